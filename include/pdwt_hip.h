@@ -1,0 +1,178 @@
+/*
+ * pdwt_hip.h -- C-ABI of the MI355X-native PDWT hot path (libpdwt_hip.so).
+ *
+ * This is the drop-in boundary: every entry point below replaces one host-callable function of
+ * the reference's level-driver layer (L2 in SURVEY.md section 1), which is the only thing the
+ * reference's `Wavelets` class (src/wt.cu) calls to do device work.  Signatures are plain C:
+ * device pointers, a host array of device pointers for the coefficient bands, a POD geometry
+ * struct passed by value (== reference `w_info`, src/utils.h:9-19) and int error codes.  No HIP,
+ * torch or C++ types appear, so the host side (include/wt.h + pdwt_amd/csrc/wt.cpp) builds with
+ * a plain host compiler (g++) and any FFI (ctypes / Cython / cgo) can bind it.
+ *
+ * Differences from the reference seam, on purpose:
+ *   - the filter bank is an ARGUMENT (per-instance state) instead of process-global
+ *     __constant__ memory uploaded at construction (src/separable.cu:48-51, quirk B-1);
+ *   - every function returns 0 on success or a negative PDWT_E* code (the reference's drivers
+ *     always return 0 and never check a CUDA call, src/wt.cu:14-21 / B-10);
+ *   - precision is a suffix (_f32/_f64) rather than a compile-time DTYPE macro, so one kernel
+ *     library serves both libpdwt.so and libpdwtd.so (Makefile:29-39 of the reference).
+ *
+ * All device work is enqueued on ONE non-NULL HIP stream per device owned by the library
+ * (pdwt_get_stream()); nothing synchronises with the host except the functions documented to.
+ */
+#ifndef PDWT_HIP_H
+#define PDWT_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDWT_MAX_FILTER_WIDTH 40 /* reference: MAX_FILTER_WIDTH, src/common.h:15 */
+
+/* error codes (negative), 0 = success */
+#define PDWT_OK 0
+#define PDWT_EINVAL (-1)   /* bad argument (NULL pointer, bad geometry, hlen out of range) */
+#define PDWT_EUNKNOWN (-2) /* unknown wavelet name (same value as src/separable.cu:42-45) */
+#define PDWT_EHIP (-3)     /* a HIP runtime call failed (see pdwt_last_error_string) */
+#define PDWT_ENOMEM (-4)
+
+/* == reference `struct w_info`, src/utils.h:9-19 (same field order, 6 x int32) */
+typedef struct pdwt_info {
+    int ndims;   /* 1 = (batched) 1D along rows, 2 = 2D */
+    int Nr;      /* rows (1D: number of signals in the batch) */
+    int Nc;      /* columns (1D: samples per signal) */
+    int nlevels; /* decomposition levels */
+    int do_swt;  /* 1 = stationary (undecimated, a-trous) transform */
+    int hlen;    /* filter length */
+} pdwt_info;
+
+/* The four 1-D filters of a bank, indexed exactly like pywt.Wavelet.filter_bank /
+ * the reference's c_kern_L/H/IL/IH (src/common.h:28-31): L=dec_lo, H=dec_hi, IL=rec_lo, IH=rec_hi. */
+typedef struct pdwt_filters_f32 {
+    int hlen;
+    float L[PDWT_MAX_FILTER_WIDTH], H[PDWT_MAX_FILTER_WIDTH], IL[PDWT_MAX_FILTER_WIDTH], IH[PDWT_MAX_FILTER_WIDTH];
+} pdwt_filters_f32;
+typedef struct pdwt_filters_f64 {
+    int hlen;
+    double L[PDWT_MAX_FILTER_WIDTH], H[PDWT_MAX_FILTER_WIDTH], IL[PDWT_MAX_FILTER_WIDTH], IH[PDWT_MAX_FILTER_WIDTH];
+} pdwt_filters_f64;
+
+/* ---------------------------------------------------------------------------------------------
+ * Device / memory plumbing.  Replaces the bare cudaMalloc/cudaMemcpy/cudaMemset/cudaFree calls
+ * the reference's class makes (src/wt.cu:117-130,421-468; src/common.cu:400-488) and the
+ * cudaGetDeviceProperties call in print_informations (src/wt.cu:543-549).
+ * ------------------------------------------------------------------------------------------- */
+int pdwt_device_count(void);                 /* >=0, or PDWT_EHIP */
+int pdwt_set_device(int dev);                /* reference has none (TODO.txt:15) */
+int pdwt_get_device(void);
+int pdwt_device_name(char* buf, int buflen); /* src/wt.cu:543-549 */
+void* pdwt_malloc(size_t nbytes);            /* NULL on failure */
+int pdwt_free(void* dptr);
+int pdwt_memset(void* dptr, int byte, size_t nbytes);              /* stream-ordered */
+int pdwt_memcpy_h2d(void* dst, const void* src, size_t nbytes);    /* blocking */
+int pdwt_memcpy_d2h(void* dst, const void* src, size_t nbytes);    /* blocking (syncs the stream) */
+int pdwt_memcpy_d2d(void* dst, const void* src, size_t nbytes);    /* stream-ordered */
+int pdwt_sync(void);                         /* wait for the library stream of the current device */
+void* pdwt_get_stream(void);                 /* the hipStream_t all launches go to (opaque) */
+const char* pdwt_last_error_string(void);    /* text of the last failing HIP call (thread-local) */
+
+/* timing helpers for bench.py: HIP events recorded on the library stream */
+void* pdwt_event_create(void);
+int pdwt_event_record(void* ev);
+int pdwt_event_sync(void* ev);
+float pdwt_event_elapsed_ms(void* ev_start, void* ev_stop); /* <0 on error */
+int pdwt_event_destroy(void* ev);
+/* Per-kernel timing: when enabled, every kernel launch of the library on this thread is bracketed
+ * by HIP events; pdwt_ktime_read() synchronises and returns {launch count, total ms} for the
+ * kernel `kernel_id` (PDWT_K_* below) since the last reset.  Off by default (no events recorded). */
+int pdwt_ktime_enable(int on);
+int pdwt_ktime_reset(void);
+int pdwt_ktime_read(int kernel_id, int* n_launches, double* total_ms);
+const char* pdwt_kernel_name(int kernel_id); /* NULL if out of range */
+int pdwt_kernel_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Filters.  Replaces w_compute_filters_separable (src/separable.cu:19-54, src/separable.h:5):
+ * same name lookup (case-insensitive, 72 names of src/filters.cpp:5919-6002, haar aliases
+ * short-circuit when !do_swt) and same return value (hlen, or -2 when unknown), but the taps are
+ * written to *out (may be NULL to only query hlen) instead of device constant memory.
+ * ------------------------------------------------------------------------------------------- */
+int pdwt_compute_filters_separable_f32(const char* wname, int do_swt, pdwt_filters_f32* out);
+int pdwt_compute_filters_separable_f64(const char* wname, int do_swt, pdwt_filters_f64* out);
+int pdwt_num_wavelets(void);                  /* 72 */
+const char* pdwt_wavelet_name(int idx);       /* table order of src/filters.cpp:5919-6002 */
+
+/* ---------------------------------------------------------------------------------------------
+ * Coefficient buffers.  Replace w_create/free/copy_coeffs_buffer[_1d]
+ * (src/common.h:62-68, src/common.cu:400-488).  Layout (host array of device pointers):
+ *   2D: [A_L, H1,V1,D1, ..., H_L,V_L,D_L] (3L+1 bands), 1D: [A_L, D1..D_L] (L+1 bands);
+ *   level i band size = ceil-halved i times (src/utils.cu:24-27), SWT: all bands Nr x Nc;
+ *   band 0 is allocated at level-1 size (it doubles as scratch, src/common.cu:421-423).
+ * All bands live in ONE device allocation (band pointers are 256-byte aligned offsets into it),
+ * zero-filled; free with pdwt_free_coeffs_buffer_*.
+ * ------------------------------------------------------------------------------------------- */
+float** pdwt_create_coeffs_buffer_f32(pdwt_info info);   /* dispatches on info.ndims */
+double** pdwt_create_coeffs_buffer_f64(pdwt_info info);
+int pdwt_free_coeffs_buffer_f32(float** coeffs, pdwt_info info);
+int pdwt_free_coeffs_buffer_f64(double** coeffs, pdwt_info info);
+int pdwt_copy_coeffs_buffer_f32(float** dst, float** src, pdwt_info info);
+int pdwt_copy_coeffs_buffer_f64(double** dst, double** src, pdwt_info info);
+/* number of bands and element count of band `num` (the arithmetic of src/wt.cu:441-465,480-504) */
+int pdwt_num_bands(pdwt_info info);
+long long pdwt_band_size(pdwt_info info, int num, int* band_Nr, int* band_Nc);
+
+/* ---------------------------------------------------------------------------------------------
+ * Transform drivers.  One per reference driver, same argument meaning:
+ *   (d_image, d_coeffs /+host array of device ptrs+/, d_tmp /+2*Nr*Nc elements+/, info by value)
+ * + the filter bank.  Observable effects are the reference's: forward fills every band and
+ * leaves d_image intact; inverse overwrites d_image and clobbers band 0 (src/wt.cu:273-307,
+ * SURVEY B-5/B-6).  Scratch usage inside d_tmp is an implementation detail.
+ *   forward_separable      <- w_forward_separable        src/separable.cu:179-209
+ *   forward_separable_1d   <- w_forward_separable_1d     src/separable.cu:214-236
+ *   inverse_separable      <- w_inverse_separable        src/separable.cu:332-364
+ *   inverse_separable_1d   <- w_inverse_separable_1d     src/separable.cu:368-395
+ *   forward_swt_separable[_1d] <- src/separable.cu:496-537
+ *   inverse_swt_separable[_1d] <- src/separable.cu:629-672
+ *   haar_forward2d/inverse2d/forward1d/inverse1d <- src/haar.cu:61-119,163-221
+ * ------------------------------------------------------------------------------------------- */
+#define PDWT_DECL_DRIVERS(T, S)                                                                               \
+    int pdwt_forward_separable_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info, const pdwt_filters_##S* f);       \
+    int pdwt_forward_separable_1d_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info, const pdwt_filters_##S* f);    \
+    int pdwt_inverse_separable_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info, const pdwt_filters_##S* f);       \
+    int pdwt_inverse_separable_1d_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info, const pdwt_filters_##S* f);    \
+    int pdwt_forward_swt_separable_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info, const pdwt_filters_##S* f);   \
+    int pdwt_forward_swt_separable_1d_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info, const pdwt_filters_##S* f);\
+    int pdwt_inverse_swt_separable_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info, const pdwt_filters_##S* f);   \
+    int pdwt_inverse_swt_separable_1d_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info, const pdwt_filters_##S* f);\
+    int pdwt_haar_forward2d_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info);                                     \
+    int pdwt_haar_inverse2d_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info);                                     \
+    int pdwt_haar_forward1d_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info);                                     \
+    int pdwt_haar_inverse1d_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info);
+PDWT_DECL_DRIVERS(float, f32)
+PDWT_DECL_DRIVERS(double, f64)
+
+/* ---------------------------------------------------------------------------------------------
+ * Coefficient utilities on the hot path (BASELINE.json north_star: soft_threshold, norm1).
+ *   soft_thresh <- w_call_soft_thresh  src/common.cu:219-249 (+ kernels src/common.cu:13-52):
+ *                  in-place copysign(max(|v|-beta,0),v) on every detail band, band 0 only when
+ *                  do_thresh_appcoeffs; normalize>0 divides beta by sqrt(2) per level.
+ *                  ONE launch for all bands (device-side band table) instead of L launches.
+ *   norm1       <- Wavelets::norm1  src/wt.cu:398-418 (3L+1 cublas asum calls): sum of |c| over
+ *                  ALL bands incl. band 0.  One reduction launch (wave64 shuffles -> LDS ->
+ *                  per-block double partial) + one finalize launch; the result is accumulated in
+ *                  double and rounded once; *out is written after a stream sync.
+ * ------------------------------------------------------------------------------------------- */
+int pdwt_soft_thresh_f32(float** d_coeffs, float beta, pdwt_info info, int do_thresh_appcoeffs, int normalize);
+int pdwt_soft_thresh_f64(double** d_coeffs, double beta, pdwt_info info, int do_thresh_appcoeffs, int normalize);
+int pdwt_norm1_f32(float** d_coeffs, pdwt_info info, float* out);
+int pdwt_norm1_f64(double** d_coeffs, pdwt_info info, double* out);
+/* same reduction, result in double regardless of T (used to combine shards across GPUs) */
+int pdwt_norm1_as_double_f32(float** d_coeffs, pdwt_info info, double* out);
+int pdwt_norm1_as_double_f64(double** d_coeffs, pdwt_info info, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDWT_HIP_H */

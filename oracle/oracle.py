@@ -1,0 +1,202 @@
+"""ctypes front-end of the CPU oracle (oracle/libpdwt_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- see the header of oracle/pdwt_oracle.c.  Importable from tests/,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of bench.py; never from pdwt_amd/.
+
+``OracleWavelets`` mirrors the reference's ``Wavelets`` class (src/wt.h:20-76, src/wt.cu) on the
+host so that parity tests read like calls on the real thing: same constructor arguments, same
+level clamping (src/wt.cu:155-165), same variant dispatch (src/wt.cu:247-266,283-301), same band
+numbering for ``get_coeff`` (src/wt.cu:475-508), same state machine (src/wt.h:8-17).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+W_INIT, W_FORWARD, W_INVERSE, W_THRESHOLD, W_CREATION_ERROR = 0, 1, 2, 3, 4
+
+
+class Info(C.Structure):  # == w_info, src/utils.h:9-19
+    _fields_ = [("ndims", C.c_int), ("Nr", C.c_int), ("Nc", C.c_int), ("nlevels", C.c_int), ("do_swt", C.c_int), ("hlen", C.c_int)]
+
+
+def _filters_struct(ct):
+    class F(C.Structure):
+        _fields_ = [("hlen", C.c_int), ("L", ct * 40), ("H", ct * 40), ("IL", ct * 40), ("IH", ct * 40)]
+    return F
+
+
+Filters32 = _filters_struct(C.c_float)
+Filters64 = _filters_struct(C.c_double)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libpdwt_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("pdwt_oracle.c", "pdwt_oracle_impl.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_norm1_f32.restype = C.c_double
+        _LIB.orc_norm1_f64.restype = C.c_double
+    return _LIB
+
+
+def div2(n):  # w_div2, src/utils.cu:24-27
+    return (n + 1) // 2
+
+
+def ilog2(i):  # w_ilog2, src/utils.cu:14-20
+    l = 0
+    while i > 1:
+        i >>= 1
+        l += 1
+    return l
+
+
+def set_num_threads(n):
+    return lib().orc_set_num_threads(int(n))
+
+
+def max_threads():
+    return lib().orc_get_max_threads()
+
+
+def filters(wname, dtype=np.float32, do_swt=0):
+    """(hlen, dict L/H/IL/IH as numpy) or raises KeyError for unknown names (rc -2)."""
+    f = Filters32() if np.dtype(dtype) == np.float32 else Filters64()
+    fn = lib().orc_compute_filters_f32 if np.dtype(dtype) == np.float32 else lib().orc_compute_filters_f64
+    h = fn(wname.encode(), int(do_swt), C.byref(f))
+    if h <= 0:
+        raise KeyError(wname)
+    return h, {k: np.array(getattr(f, k)[:h], dtype=dtype) for k in ("L", "H", "IL", "IH")}, f
+
+
+def band_shapes(Nr, Nc, nlevels, do_swt, ndims):
+    """Shapes of the logical bands [A_L, details...] in PDWT order (src/common.cu:400-445)."""
+    shapes = []
+    r, c = Nr, Nc
+    for _ in range(nlevels):
+        if not do_swt:
+            if ndims == 2:
+                r = div2(r)
+            c = div2(c)
+        shapes += [(r, c)] * (3 if ndims == 2 else 1)
+    return [(r, c)] + shapes
+
+
+class OracleWavelets:
+    """Host mirror of the reference's Wavelets class, computing with the C oracle."""
+
+    def __init__(self, img, wname, levels, do_swt=0, ndim=2, dtype=None, custom_filters=None):
+        img = np.asarray(img)
+        if dtype is None:
+            dtype = img.dtype if img.dtype in (np.float32, np.float64) else np.float32
+        self.dtype = np.dtype(dtype)
+        self.sfx = "f32" if self.dtype == np.float32 else "f64"
+        if img.ndim == 1:
+            img = img[None, :]
+        Nr, Nc = img.shape
+        self.state = W_INIT
+        if levels < 1:  # src/wt.cu:111-114
+            levels = 1
+        if Nr == 1:  # src/wt.cu:133-136
+            ndim = 1
+        self.wname = wname
+        self.do_swt = int(do_swt)
+        if custom_filters is not None:
+            hlen, self._F = custom_filters
+        else:
+            alias = wname.lower() in ("haar", "db1", "bior1.1", "rbior1.1")
+            if alias and not do_swt:  # src/separable.cu:24-28
+                hlen, self._F = 2, None
+            else:
+                hlen, _, self._F = filters(wname, self.dtype, do_swt)
+        N = min(Nr, Nc) if ndim == 2 else Nc
+        wmaxlev = ilog2(N // (hlen - 1))  # src/wt.cu:155-165
+        if levels > wmaxlev:
+            levels = wmaxlev
+        self.info = Info(ndim, Nr, Nc, levels, self.do_swt, hlen)
+        self.image = np.ascontiguousarray(img, dtype=self.dtype).copy()
+        self.tmp = np.zeros(2 * Nr * Nc + 64, dtype=self.dtype)
+        shapes = band_shapes(Nr, Nc, levels, self.do_swt, ndim)
+        self.shapes = shapes
+        # band 0 is allocated at level-1 size (src/common.cu:421-423, 441-443)
+        r0, c0 = (Nr, Nc) if self.do_swt else ((div2(Nr) if ndim == 2 else Nr), div2(Nc))
+        self._bufs = [np.zeros(r0 * c0, dtype=self.dtype)] + [np.zeros(s[0] * s[1], dtype=self.dtype) for s in shapes[1:]]
+        ct = C.c_float if self.dtype == np.float32 else C.c_double
+        self._PT = C.POINTER(ct)
+        self._ctab = (self._PT * len(self._bufs))(*[b.ctypes.data_as(self._PT) for b in self._bufs])
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _p(self, a):
+        return a.ctypes.data_as(self._PT)
+
+    def _driver(self, direction):
+        """Variant selection of Wavelets::forward/inverse (src/wt.cu:247-266, 283-301)."""
+        i = self.info
+        if i.hlen == 2 and not i.do_swt:
+            return "haar_%s%dd" % (direction, i.ndims), False
+        return direction + ("_swt" if i.do_swt else "") + "_separable" + ("_1d" if i.ndims == 1 else ""), True
+
+    def _call(self, direction):
+        name, needs_filters = self._driver(direction)
+        fn = getattr(lib(), "orc_%s_%s" % (name, self.sfx))
+        args = [self._p(self.image), self._ctab, self._p(self.tmp), self.info]
+        if needs_filters:
+            args.append(C.byref(self._F))
+        rc = fn(*args)
+        assert rc == 0
+
+    # -- Wavelets API ----------------------------------------------------------------------
+    def forward(self):  # src/wt.cu:236-271
+        self._call("forward")
+        self.state = W_FORWARD
+
+    def inverse(self):  # src/wt.cu:273-307
+        if self.state == W_INVERSE:
+            return
+        self._call("inverse")
+        self.state = W_INVERSE
+
+    def soft_threshold(self, beta, do_thresh_appcoeffs=0, normalize=0):  # src/wt.cu:310-317
+        if self.state == W_INVERSE:
+            return
+        fn = getattr(lib(), "orc_soft_thresh_" + self.sfx)
+        ct = C.c_float if self.dtype == np.float32 else C.c_double
+        fn(self._ctab, ct(beta), self.info, int(do_thresh_appcoeffs), int(normalize))
+
+    def norm1(self):  # src/wt.cu:398-418
+        v = getattr(lib(), "orc_norm1_" + self.sfx)(self._ctab, self.info)
+        return self.dtype.type(v)
+
+    def norm1_f64(self):
+        return float(getattr(lib(), "orc_norm1_" + self.sfx)(self._ctab, self.info))
+
+    def get_image(self):  # src/wt.cu:421-424
+        return self.image.copy()
+
+    def set_image(self, img):  # src/wt.cu:427-433
+        self.image[...] = np.asarray(img, dtype=self.dtype).reshape(self.image.shape)
+        self.state = W_INIT
+
+    def get_coeff(self, num):  # src/wt.cu:475-508
+        r, c = self.shapes[num]
+        return self._bufs[num][: r * c].reshape(r, c).copy()
+
+    def set_coeff(self, arr, num):  # src/wt.cu:436-468
+        r, c = self.shapes[num]
+        self._bufs[num][: r * c] = np.asarray(arr, dtype=self.dtype).reshape(-1)
+
+    @property
+    def coeffs(self):
+        return [self.get_coeff(i) for i in range(len(self.shapes))]
