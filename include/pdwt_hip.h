@@ -137,6 +137,14 @@ long long pdwt_band_size(pdwt_info info, int num, int* band_Nr, int* band_Nc);
  *   inverse_swt_separable[_1d] <- src/separable.cu:629-672
  *   haar_forward2d/inverse2d/forward1d/inverse1d <- src/haar.cu:61-119,163-221
  * ------------------------------------------------------------------------------------------- */
+/* test / tuning knobs (not part of the reference seam): key "force_twopass" = 1 makes the 2D DWT
+ * drivers use the two-pass (row kernel + column kernel) form instead of the fused level kernel. */
+int pdwt_debug_set(const char* key, int value);
+
+/* minimum element count of the d_tmp scratch the drivers need (2*Nr*Nc as in src/wt.cu:128-130,
+ * plus alignment slack for the sub-buffers carved out of it) */
+size_t pdwt_tmp_elems(pdwt_info info);
+
 #define PDWT_DECL_DRIVERS(T, S)                                                                               \
     int pdwt_forward_separable_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info, const pdwt_filters_##S* f);       \
     int pdwt_forward_separable_1d_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info, const pdwt_filters_##S* f);    \

@@ -1,0 +1,76 @@
+"""Build the native libraries of pdwt_amd IN-TREE (pdwt_amd/lib/):
+
+  libpdwt_hip.so   hand-written gfx950 kernels + the C-ABI of include/pdwt_hip.h   (hipcc)
+  libpdwt.so       host C++ `Wavelets` class, DTYPE=float                           (g++)
+  libpdwtd.so      host C++ `Wavelets` class, DTYPE=double (-DDOUBLEPRECISION)      (g++)
+
+The two host libraries mirror the reference's product shape (Makefile:29-39).  hipcc cross-compiles
+for gfx950 without a GPU, so this runs in the build container; the .so files travel to the GPU box
+with the repo snapshot.  Usage:  python -m pdwt_amd.build [--force]
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "lib")
+INC = os.path.join(ROOT, "include")
+
+HIP_SOURCES = ["runtime.hip", "coeffs.hip", "dwt.hip", "swt.hip", "haar.hip", "utils.hip", "filters.cpp"]
+HOST_SOURCES = ["wt.cpp", "wt_capi.cpp"]
+HIP_DEPS = ["common.hpp", "filters_table.inc"]
+ARCH = "gfx950"
+
+
+def _newer(srcs, out):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP library cannot be built")
+
+
+def build_hip(force=False):
+    out = os.path.join(LIB, "libpdwt_hip.so")
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, d) for d in HIP_DEPS] + [os.path.join(INC, "pdwt_hip.h")]
+    if force or _newer(deps, out):
+        os.makedirs(LIB, exist_ok=True)
+        _run([hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", out] + srcs)
+    return out
+
+
+def build_host(force=False):
+    outs = []
+    srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(INC, "wt.h"), os.path.join(INC, "pdwt_hip.h")]
+    for name, flags in (("libpdwt.so", []), ("libpdwtd.so", ["-DDOUBLEPRECISION"])):
+        out = os.path.join(LIB, name)
+        if force or _newer(deps + [os.path.join(LIB, "libpdwt_hip.so")], out):
+            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall"] + flags + ["-o", out] + srcs
+                 + ["-L" + LIB, "-lpdwt_hip", "-Wl,-rpath,$ORIGIN"])
+        outs.append(out)
+    return outs
+
+
+def build_all(force=False):
+    return [build_hip(force)] + build_host(force)
+
+
+if __name__ == "__main__":
+    for p in build_all("--force" in sys.argv):
+        print(p)

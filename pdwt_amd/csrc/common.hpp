@@ -1,0 +1,123 @@
+// common.hpp -- internals shared by the HIP translation units of libpdwt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/pdwt_hip.h"
+
+namespace pdwt {
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void set_last_error(hipError_t e, const char* what, const char* file, int line);
+
+#define PDWT_HIP_TRY(expr)                                              \
+    do {                                                                \
+        hipError_t _e = (expr);                                         \
+        if (_e != hipSuccess) {                                         \
+            ::pdwt::set_last_error(_e, #expr, __FILE__, __LINE__);      \
+            return PDWT_EHIP;                                           \
+        }                                                               \
+    } while (0)
+
+// ---- stream + per-kernel timing ---------------------------------------------------------------
+hipStream_t stream();  // the library stream of the current device (created lazily, non-blocking)
+
+// kernel ids for pdwt_ktime_* (names in runtime.hip must stay in this order)
+enum KernelId {
+    K_FWD2D_FUSED = 0,
+    K_INV2D_FUSED,
+    K_ANA_ROWS,
+    K_ANA_COLS,
+    K_SYN_COLS,
+    K_SYN_ROWS,
+    K_SWT_ANA_ROWS,
+    K_SWT_ANA_COLS,
+    K_SWT_SYN_COLS,
+    K_SWT_SYN_ROWS,
+    K_HAAR2D_FWD,
+    K_HAAR2D_INV,
+    K_HAAR1D_FWD,
+    K_HAAR1D_INV,
+    K_SOFT_THRESH,
+    K_ABS_SUM,
+    K_ABS_SUM_FINAL,
+    K_COUNT
+};
+
+// Bracket a launch with events when pdwt_ktime_enable(1) is active; otherwise free.
+struct KTimer {
+    int id;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    explicit KTimer(int kernel_id);
+    ~KTimer();
+};
+
+// ---- size rule --------------------------------------------------------------------------------
+// ceil-half: reference w_div2, src/utils.cu:24-27
+__host__ __device__ inline int div2(int n) { return (n + 1) >> 1; }
+inline int idiv_up(int a, int b) { return (a + b - 1) / b; }
+
+// ---- periodic index helpers (device) ------------------------------------------------------------
+// Index into a length-n line after the virtual "repeat last sample when n is odd" extension,
+// then periodisation (reference src/separable.cu:116-121, SURVEY A-1).  Full modulo: equals the
+// reference's single wrap whenever that is valid and stays in-bounds for any tile overhang.
+__device__ __forceinline__ int wrap_ext(int s, int n)
+{
+    const int np = n + (n & 1);
+    if ((unsigned)s >= (unsigned)np) {
+        s %= np;
+        if (s < 0) s += np;
+    }
+    return (s == n) ? n - 1 : s;
+}
+// plain periodic index (synthesis and a-trous passes, src/separable.cu:270-273,430-433)
+__device__ __forceinline__ int wrap_per(int s, int n)
+{
+    if ((unsigned)s >= (unsigned)n) {
+        s %= n;
+        if (s < 0) s += n;
+    }
+    return s;
+}
+
+// Two filters of a bank passed BY VALUE in the kernarg segment: the taps arrive through scalar
+// loads (SGPRs / scalar cache), no __constant__ symbol, no per-process global state (SURVEY B-1).
+template <typename T>
+struct Taps2 {
+    T a[PDWT_MAX_FILTER_WIDTH];
+    T b[PDWT_MAX_FILTER_WIDTH];
+};
+
+template <typename T> struct FiltersOf;
+template <> struct FiltersOf<float> { using type = pdwt_filters_f32; };
+template <> struct FiltersOf<double> { using type = pdwt_filters_f64; };
+
+template <typename T>
+inline Taps2<T> taps_fwd(const typename FiltersOf<T>::type* f)
+{
+    Taps2<T> t;
+    for (int i = 0; i < PDWT_MAX_FILTER_WIDTH; i++) { t.a[i] = f->L[i]; t.b[i] = f->H[i]; }
+    return t;
+}
+template <typename T>
+inline Taps2<T> taps_inv(const typename FiltersOf<T>::type* f, T scale = T(1))
+{
+    Taps2<T> t;
+    for (int i = 0; i < PDWT_MAX_FILTER_WIDTH; i++) { t.a[i] = f->IL[i] * scale; t.b[i] = f->IH[i] * scale; }
+    return t;
+}
+
+template <typename T> __device__ __forceinline__ T fma_t(T a, T b, T c);
+template <> __device__ __forceinline__ float fma_t<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <> __device__ __forceinline__ double fma_t<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// band-size bookkeeping shared by coeffs.hip / utils
+struct BandGeom {
+    int nbands;
+    int Nr[3 * 32 + 1], Nc[3 * 32 + 1];
+    size_t alloc_elems[3 * 32 + 1];  // allocation size (band 0 is level-1 sized)
+};
+int band_geometry(const pdwt_info& w, BandGeom* g);  // PDWT_OK / PDWT_EINVAL
+
+}  // namespace pdwt

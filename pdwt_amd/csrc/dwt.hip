@@ -1,0 +1,671 @@
+// dwt.hip -- decimating separable DWT: per-level kernels + level drivers (gfx950 / CDNA4).
+//
+// Path replaced: reference src/separable.cu:91-395 (w_kern_forward_pass1/2, w_kern_inverse_pass1/2
+// and the four level drivers).  Math: SURVEY.md Appendix A-1 / A-2; the per-sample tap order and the
+// one-FMA-per-tap accumulation are the reference's, so results are bit-identical to the CPU oracle.
+//
+// MI355X design (not the reference's 16x16-thread, one-global-load-per-tap structure):
+//   * one FUSED kernel per level for 2D (row pass + column pass through LDS): every input sample is
+//     read from HBM once per level (+ tile halo), the four bands are written once; the reference
+//     round-trips two half-width temporaries through memory per level;
+//   * x is the lane axis everywhere (64 consecutive columns per wave) so global accesses coalesce
+//     into full 256-byte segments; periodic halos are resolved while the tile is staged into LDS;
+//   * taps travel by value in the kernarg segment (scalar loads), not in __constant__ memory;
+//   * long filters whose fused tile would not leave >= 2 workgroups per CU fall back to two LDS-tiled
+//     1-D passes (k_ana_rows + k_ana_cols / k_syn_cols + k_syn_rows), which are also the batched-1D
+//     transform (reference: "2D separable transform without the second pass", src/separable.cu:213).
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.hpp"
+
+namespace pdwt {
+
+constexpr int kThreads = 256;  // 4 x wave64
+
+// -------------------------------------------------------------------------------------------------
+// 2D forward level, fused.  Block = TY x TX outputs of each band.
+//   stage  (2TY+hlen-2) x (2TX+hlen-2) inputs -> LDS   (wrap: A-1 "virtual replicate then periodic")
+//   rows   lo/hi[r][i] = sum_j in[r][2i+j] * L/H[hlen-1-j]
+//   cols   A,H = L/H over lo ; V,D = L/H over hi        (reference pass2: src/separable.cu:135-176)
+// -------------------------------------------------------------------------------------------------
+template <typename T, int HLEN, int TX, int TY>
+__global__ __launch_bounds__(kThreads) void k_fwd2d_fused(const T* __restrict__ in, T* __restrict__ cA, T* __restrict__ cH,
+                                                           T* __restrict__ cV, T* __restrict__ cD, int Nr, int Nc, int hlen_rt,
+                                                           Taps2<T> f)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int hlen = HLEN > 0 ? HLEN : hlen_rt;
+    const int c = (hlen & 1) ? hlen / 2 : hlen / 2 - 1;
+    const int RIN = 2 * TY + hlen - 2;
+    const int CIN = 2 * TX + hlen - 2;
+    const int CINP = CIN | 1;  // odd row pitch: the stride-2 row-pass reads spread over all banks
+    T* s_in = reinterpret_cast<T*>(smem);
+    T* s_lo = s_in + RIN * CINP;
+    T* s_hi = s_lo + RIN * TX;
+
+    const int Nr2 = div2(Nr), Nc2 = div2(Nc);
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const int xb = 2 * x0 - c, yb = 2 * y0 - c;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+
+    // stage the input tile (interior tiles: no wrap taken; edge tiles: periodic / replicate rule)
+    const bool interior = (xb >= 0) && (xb + CIN <= Nc) && (yb >= 0) && (yb + RIN <= Nr);
+    if (interior) {
+        for (int r = ty; r < RIN; r += 4) {
+            const T* row = in + (size_t)(yb + r) * Nc + xb;
+            for (int cc = tx; cc < CIN; cc += 64) s_in[r * CINP + cc] = row[cc];
+        }
+    } else {
+        for (int r = ty; r < RIN; r += 4) {
+            const T* row = in + (size_t)wrap_ext(yb + r, Nr) * Nc;
+            for (int cc = tx; cc < CIN; cc += 64) s_in[r * CINP + cc] = row[wrap_ext(xb + cc, Nc)];
+        }
+    }
+    __syncthreads();
+
+    // row pass
+    for (int r = ty; r < RIN; r += 4) {
+        const T* p = s_in + r * CINP + 2 * tx;
+        T lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < hlen; j++) {
+            const T v = p[j];
+            lo = fma_t(v, f.a[hlen - 1 - j], lo);
+            hi = fma_t(v, f.b[hlen - 1 - j], hi);
+        }
+        s_lo[r * TX + tx] = lo;
+        s_hi[r * TX + tx] = hi;
+    }
+    __syncthreads();
+
+    // column pass + store
+    const int gx = x0 + tx;
+    for (int y = ty; y < TY; y += 4) {
+        T a = 0, h = 0, v = 0, d = 0;
+        const T* pl = s_lo + (2 * y) * TX + tx;
+        const T* ph = s_hi + (2 * y) * TX + tx;
+#pragma unroll
+        for (int j = 0; j < hlen; j++) {
+            const T l = pl[j * TX], g = ph[j * TX];
+            const T fl = f.a[hlen - 1 - j], fh = f.b[hlen - 1 - j];
+            a = fma_t(l, fl, a);
+            h = fma_t(l, fh, h);
+            v = fma_t(g, fl, v);
+            d = fma_t(g, fh, d);
+        }
+        const int gy = y0 + y;
+        if (gy < Nr2 && gx < Nc2) {
+            const size_t o = (size_t)gy * Nc2 + gx;
+            cA[o] = a;
+            cH[o] = h;
+            cV[o] = v;
+            cD[o] = d;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// 2D inverse level, fused.  Block = (2TY) x (2TX) output samples from a (TY+h2) x (TX+h2) tile of
+// each of the four bands.  Column synthesis first (reference pass1, src/separable.cu:246-289), row
+// synthesis second (pass2, :293-328); math A-2.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int HLEN, int TX, int TY>
+__global__ __launch_bounds__(kThreads) void k_inv2d_fused(const T* __restrict__ cA, const T* __restrict__ cH, const T* __restrict__ cV,
+                                                           const T* __restrict__ cD, T* __restrict__ out, int Nri, int Nci, int Nro,
+                                                           int Nco, int hlen_rt, Taps2<T> f)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int hlen = HLEN > 0 ? HLEN : hlen_rt;
+    const int h2 = hlen / 2;
+    const int c = h2 / 2;
+    const int shift = (h2 & 1) ? 0 : 1;
+    const int RC = TY + h2;
+    const int CC = TX + h2;
+    const int CCP = CC | 1;
+    T* s_A = reinterpret_cast<T*>(smem);
+    T* s_H = s_A + RC * CCP;
+    T* s_V = s_H + RC * CCP;
+    T* s_D = s_V + RC * CCP;
+    T* s_t1 = s_D + RC * CCP;  // (2TY) x CCP
+    T* s_t2 = s_t1 + 2 * TY * CCP;
+
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;  // coefficient coordinates
+    const int xb = x0 - c, yb = y0 - c;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+
+    const bool interior = (xb >= 0) && (xb + CC <= Nci) && (yb >= 0) && (yb + RC <= Nri);
+    for (int r = ty; r < RC; r += 4) {
+        const size_t ro = (size_t)(interior ? yb + r : wrap_per(yb + r, Nri)) * Nci;
+        for (int cc = tx; cc < CC; cc += 64) {
+            const size_t o = ro + (interior ? xb + cc : wrap_per(xb + cc, Nci));
+            const int s = r * CCP + cc;
+            s_A[s] = cA[o];
+            s_H[s] = cH[o];
+            s_V[s] = cV[o];
+            s_D[s] = cD[o];
+        }
+    }
+    __syncthreads();
+
+    // column synthesis: t1 = A*IL + H*IH, t2 = V*IL + D*IH for the 2TY output rows of this tile
+    for (int gyl = ty; gyl < 2 * TY; gyl += 4) {
+        const int gp = gyl + shift;  // 2*y0 is even, so parity/halving can be done tile-locally
+        const int pl = gp >> 1, off = 1 - (gp & 1);
+        for (int cc = tx; cc < CC; cc += 64) {
+            T sa = 0, sh = 0, sv = 0, sd = 0;
+            const int base = pl * CCP + cc;
+#pragma unroll
+            for (int j = 0; j < h2; j++) {
+                const int k = hlen - 1 - (2 * j + off);
+                const T fl = f.a[k], fh = f.b[k];
+                const int s = base + j * CCP;
+                sa = fma_t(s_A[s], fl, sa);
+                sh = fma_t(s_H[s], fh, sh);
+                sv = fma_t(s_V[s], fl, sv);
+                sd = fma_t(s_D[s], fh, sd);
+            }
+            s_t1[gyl * CCP + cc] = sa + sh;
+            s_t2[gyl * CCP + cc] = sv + sd;
+        }
+    }
+    __syncthreads();
+
+    // row synthesis + store: out = t1*IL + t2*IH
+    for (int gyl = ty; gyl < 2 * TY; gyl += 4) {
+        const int gy = 2 * y0 + gyl;
+        if (gy >= Nro) break;
+        for (int gxl = tx; gxl < 2 * TX; gxl += 64) {
+            const int gp = gxl + shift;
+            const int pl = gp >> 1, off = 1 - (gp & 1);
+            T s1 = 0, s2 = 0;
+            const int base = gyl * CCP + pl;
+#pragma unroll
+            for (int j = 0; j < h2; j++) {
+                const int k = hlen - 1 - (2 * j + off);
+                s1 = fma_t(s_t1[base + j], f.a[k], s1);
+                s2 = fma_t(s_t2[base + j], f.b[k], s2);
+            }
+            const int gx = 2 * x0 + gxl;
+            if (gx < Nco) out[(size_t)gy * Nco + gx] = s1 + s2;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// 1-D analysis along rows (batched-1D forward level; row half of the two-pass 2D fallback).
+// Block = 4 rows (one per wave) x TXO outputs.  in: Nr x Nc  ->  lo, hi: Nr x ceil(Nc/2).
+// -------------------------------------------------------------------------------------------------
+template <typename T, int HLEN, int TXO>
+__global__ __launch_bounds__(kThreads) void k_ana_rows(const T* __restrict__ in, T* __restrict__ lo, T* __restrict__ hi, int Nr, int Nc,
+                                                        int hlen_rt, Taps2<T> f)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int hlen = HLEN > 0 ? HLEN : hlen_rt;
+    const int c = (hlen & 1) ? hlen / 2 : hlen / 2 - 1;
+    const int CIN = 2 * TXO + hlen - 2;
+    const int CINP = CIN | 1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    T* s = reinterpret_cast<T*>(smem) + w * CINP;
+    const int Nc2 = div2(Nc);
+    const int x0 = blockIdx.x * TXO;
+    const int xb = 2 * x0 - c;
+    const int row = blockIdx.y * 4 + w;
+    if (row < Nr) {
+        const T* src = in + (size_t)row * Nc;
+        if (xb >= 0 && xb + CIN <= Nc) {
+            for (int cc = lane; cc < CIN; cc += 64) s[cc] = src[xb + cc];
+        } else {
+            for (int cc = lane; cc < CIN; cc += 64) s[cc] = src[wrap_ext(xb + cc, Nc)];
+        }
+    }
+    __syncthreads();
+    if (row >= Nr) return;
+    for (int i = lane; i < TXO; i += 64) {
+        const int gx = x0 + i;
+        if (gx >= Nc2) break;
+        const T* p = s + 2 * i;
+        T l = 0, h = 0;
+#pragma unroll
+        for (int j = 0; j < hlen; j++) {
+            const T v = p[j];
+            l = fma_t(v, f.a[hlen - 1 - j], l);
+            h = fma_t(v, f.b[hlen - 1 - j], h);
+        }
+        lo[(size_t)row * Nc2 + gx] = l;
+        hi[(size_t)row * Nc2 + gx] = h;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// 1-D analysis along columns of two inputs (column half of the two-pass 2D fallback).
+// t1,t2: Nr x Ncw -> A,H (from t1) and V,D (from t2): ceil(Nr/2) x Ncw.  Block = TYO x 64 outputs.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int HLEN, int TYO>
+__global__ __launch_bounds__(kThreads) void k_ana_cols(const T* __restrict__ t1, const T* __restrict__ t2, T* __restrict__ cA,
+                                                        T* __restrict__ cH, T* __restrict__ cV, T* __restrict__ cD, int Nr, int Ncw,
+                                                        int hlen_rt, Taps2<T> f)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int hlen = HLEN > 0 ? HLEN : hlen_rt;
+    const int c = (hlen & 1) ? hlen / 2 : hlen / 2 - 1;
+    const int RIN = 2 * TYO + hlen - 2;
+    T* s1 = reinterpret_cast<T*>(smem);
+    T* s2 = s1 + RIN * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int Nr2 = div2(Nr);
+    const int gx = blockIdx.x * 64 + tx;
+    const int y0 = blockIdx.y * TYO;
+    const int yb = 2 * y0 - c;
+    if (gx < Ncw) {
+        for (int r = ty; r < RIN; r += 4) {
+            const size_t o = (size_t)wrap_ext(yb + r, Nr) * Ncw + gx;
+            s1[r * 64 + tx] = t1[o];
+            s2[r * 64 + tx] = t2[o];
+        }
+    }
+    __syncthreads();
+    if (gx >= Ncw) return;
+    for (int y = ty; y < TYO; y += 4) {
+        const int gy = y0 + y;
+        if (gy >= Nr2) break;
+        T a = 0, h = 0, v = 0, d = 0;
+        const T* p1 = s1 + (2 * y) * 64 + tx;
+        const T* p2 = s2 + (2 * y) * 64 + tx;
+#pragma unroll
+        for (int j = 0; j < hlen; j++) {
+            const T l = p1[j * 64], g = p2[j * 64];
+            const T fl = f.a[hlen - 1 - j], fh = f.b[hlen - 1 - j];
+            a = fma_t(l, fl, a);
+            h = fma_t(l, fh, h);
+            v = fma_t(g, fl, v);
+            d = fma_t(g, fh, d);
+        }
+        const size_t o = (size_t)gy * Ncw + gx;
+        cA[o] = a;
+        cH[o] = h;
+        cV[o] = v;
+        cD[o] = d;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// 1-D synthesis along columns: (A,H) -> t1, (V,D) -> t2.  Bands: Nri x Nc, outputs: Nro x Nc.
+// Block = 64 columns x TYC coefficient rows (2*TYC output rows).
+// -------------------------------------------------------------------------------------------------
+template <typename T, int HLEN, int TYC>
+__global__ __launch_bounds__(kThreads) void k_syn_cols(const T* __restrict__ cA, const T* __restrict__ cH, const T* __restrict__ cV,
+                                                        const T* __restrict__ cD, T* __restrict__ t1, T* __restrict__ t2, int Nri,
+                                                        int Nc, int Nro, int hlen_rt, Taps2<T> f)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int hlen = HLEN > 0 ? HLEN : hlen_rt;
+    const int h2 = hlen / 2;
+    const int c = h2 / 2;
+    const int shift = (h2 & 1) ? 0 : 1;
+    const int RC = TYC + h2;
+    T* s_A = reinterpret_cast<T*>(smem);
+    T* s_H = s_A + RC * 64;
+    T* s_V = s_H + RC * 64;
+    T* s_D = s_V + RC * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int gx = blockIdx.x * 64 + tx;
+    const int y0 = blockIdx.y * TYC;
+    const int yb = y0 - c;
+    if (gx < Nc) {
+        for (int r = ty; r < RC; r += 4) {
+            const size_t o = (size_t)wrap_per(yb + r, Nri) * Nc + gx;
+            const int s = r * 64 + tx;
+            s_A[s] = cA[o];
+            s_H[s] = cH[o];
+            s_V[s] = cV[o];
+            s_D[s] = cD[o];
+        }
+    }
+    __syncthreads();
+    if (gx >= Nc) return;
+    for (int gyl = ty; gyl < 2 * TYC; gyl += 4) {
+        const int gy = 2 * y0 + gyl;
+        if (gy >= Nro) break;
+        const int gp = gyl + shift;
+        const int pl = gp >> 1, off = 1 - (gp & 1);
+        T sa = 0, sh = 0, sv = 0, sd = 0;
+        const int base = pl * 64 + tx;
+#pragma unroll
+        for (int j = 0; j < h2; j++) {
+            const int k = hlen - 1 - (2 * j + off);
+            const T fl = f.a[k], fh = f.b[k];
+            const int s = base + j * 64;
+            sa = fma_t(s_A[s], fl, sa);
+            sh = fma_t(s_H[s], fh, sh);
+            sv = fma_t(s_V[s], fl, sv);
+            sd = fma_t(s_D[s], fh, sd);
+        }
+        t1[(size_t)gy * Nc + gx] = sa + sh;
+        t2[(size_t)gy * Nc + gx] = sv + sd;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// 1-D synthesis along rows: out = a*IL + d*IH.  a,d: Nr x Nci, out: Nr x Nco.
+// Block = 4 rows (one per wave) x TXC coefficient columns (2*TXC outputs).
+// -------------------------------------------------------------------------------------------------
+template <typename T, int HLEN, int TXC>
+__global__ __launch_bounds__(kThreads) void k_syn_rows(const T* __restrict__ a, const T* __restrict__ d, T* __restrict__ out, int Nr,
+                                                        int Nci, int Nco, int hlen_rt, Taps2<T> f)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int hlen = HLEN > 0 ? HLEN : hlen_rt;
+    const int h2 = hlen / 2;
+    const int c = h2 / 2;
+    const int shift = (h2 & 1) ? 0 : 1;
+    const int CC = TXC + h2;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    T* sa = reinterpret_cast<T*>(smem) + w * 2 * CC;
+    T* sd = sa + CC;
+    const int x0 = blockIdx.x * TXC;
+    const int xb = x0 - c;
+    const int row = blockIdx.y * 4 + w;
+    if (row < Nr) {
+        const T* pa = a + (size_t)row * Nci;
+        const T* pd = d + (size_t)row * Nci;
+        for (int cc = lane; cc < CC; cc += 64) {
+            const int sx = wrap_per(xb + cc, Nci);
+            sa[cc] = pa[sx];
+            sd[cc] = pd[sx];
+        }
+    }
+    __syncthreads();
+    if (row >= Nr) return;
+    for (int gxl = lane; gxl < 2 * TXC; gxl += 64) {
+        const int gx = 2 * x0 + gxl;
+        if (gx >= Nco) break;
+        const int gp = gxl + shift;
+        const int pl = gp >> 1, off = 1 - (gp & 1);
+        T s1 = 0, s2 = 0;
+#pragma unroll
+        for (int j = 0; j < h2; j++) {
+            const int k = hlen - 1 - (2 * j + off);
+            s1 = fma_t(sa[pl + j], f.a[k], s1);
+            s2 = fma_t(sd[pl + j], f.b[k], s2);
+        }
+        out[(size_t)row * Nco + gx] = s1 + s2;
+    }
+}
+
+// =================================================================================================
+// host side: launch helpers
+// =================================================================================================
+template <typename K>
+static int set_lds(K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024) PDWT_HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PDWT_OK;
+}
+
+// test/tuning knob: force the two-pass (row kernel + column kernel) form for 2D levels
+static int g_force_twopass = -1;
+static bool force_twopass()
+{
+    if (g_force_twopass < 0) {
+        const char* e = getenv("PDWT_FORCE_TWOPASS");
+        g_force_twopass = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_force_twopass == 1;
+}
+
+constexpr int FTX = 64, FTY = 16;           // fused tile (outputs per band / coefficient tile)
+constexpr size_t kFusedLdsBudget = 64 * 1024;  // keep >= 2 workgroups per CU (160 KiB LDS)
+
+template <typename T>
+static size_t fwd_fused_lds(int hlen)
+{
+    const int RIN = 2 * FTY + hlen - 2, CINP = (2 * FTX + hlen - 2) | 1;
+    return ((size_t)RIN * CINP + 2 * (size_t)RIN * FTX) * sizeof(T);
+}
+template <typename T>
+static size_t inv_fused_lds(int hlen)
+{
+    const int h2 = hlen / 2, RC = FTY + h2, CCP = (FTX + h2) | 1;
+    return (4 * (size_t)RC * CCP + 2 * (size_t)(2 * FTY) * CCP) * sizeof(T);
+}
+
+#define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
+
+// ---- level launchers --------------------------------------------------------------------------
+template <typename T>
+static int launch_ana_rows(const T* in, T* lo, T* hi, int Nr, int Nc, int hlen, const Taps2<T>& f)
+{
+    constexpr int TXO = 256;
+    const size_t lds = 4 * (size_t)((2 * TXO + hlen - 2) | 1) * sizeof(T);
+    dim3 grid(idiv_up(div2(Nc), TXO), idiv_up(Nr, 4));
+    KTimer kt(K_ANA_ROWS);
+    hipLaunchKernelGGL((k_ana_rows<T, 0, TXO>), grid, dim3(kThreads), lds, stream(), in, lo, hi, Nr, Nc, hlen, f);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
+template <typename T>
+static int launch_syn_rows(const T* a, const T* d, T* out, int Nr, int Nci, int Nco, int hlen, const Taps2<T>& f)
+{
+    constexpr int TXC = 128;
+    const size_t lds = 4 * 2 * (size_t)(TXC + hlen / 2) * sizeof(T);
+    dim3 grid(idiv_up(Nci, TXC), idiv_up(Nr, 4));
+    KTimer kt(K_SYN_ROWS);
+    hipLaunchKernelGGL((k_syn_rows<T, 0, TXC>), grid, dim3(kThreads), lds, stream(), a, d, out, Nr, Nci, Nco, hlen, f);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
+template <typename T>
+static int launch_ana_cols(const T* t1, const T* t2, T* cA, T* cH, T* cV, T* cD, int Nr, int Ncw, int hlen, const Taps2<T>& f)
+{
+    constexpr int TYO = 16;
+    const size_t lds = 2 * (size_t)(2 * TYO + hlen - 2) * 64 * sizeof(T);
+    auto k = k_ana_cols<T, 0, TYO>;
+    if (set_lds(k, lds) != PDWT_OK) return PDWT_EHIP;
+    dim3 grid(idiv_up(Ncw, 64), idiv_up(div2(Nr), TYO));
+    KTimer kt(K_ANA_COLS);
+    hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream(), t1, t2, cA, cH, cV, cD, Nr, Ncw, hlen, f);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
+template <typename T>
+static int launch_syn_cols(const T* cA, const T* cH, const T* cV, const T* cD, T* t1, T* t2, int Nri, int Nc, int Nro, int hlen,
+                           const Taps2<T>& f)
+{
+    constexpr int TYC = 16;
+    const size_t lds = 4 * (size_t)(TYC + hlen / 2) * 64 * sizeof(T);
+    auto k = k_syn_cols<T, 0, TYC>;
+    if (set_lds(k, lds) != PDWT_OK) return PDWT_EHIP;
+    dim3 grid(idiv_up(Nc, 64), idiv_up(Nri, TYC));
+    KTimer kt(K_SYN_COLS);
+    hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream(), cA, cH, cV, cD, t1, t2, Nri, Nc, Nro, hlen, f);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
+// one 2D forward level: in (nr x nc) -> A,H,V,D (nr2 x nc2); t1/t2 scratch for the two-pass form
+template <typename T>
+static int level_fwd2d(const T* in, T* cA, T* cH, T* cV, T* cD, T* t1, T* t2, int nr, int nc, int hlen, const Taps2<T>& f)
+{
+    const size_t lds = fwd_fused_lds<T>(hlen);
+    if (lds <= kFusedLdsBudget && !force_twopass()) {
+        dim3 grid(idiv_up(div2(nc), FTX), idiv_up(div2(nr), FTY));
+        KTimer kt(K_FWD2D_FUSED);
+        hipLaunchKernelGGL((k_fwd2d_fused<T, 0, FTX, FTY>), grid, dim3(kThreads), lds, stream(), in, cA, cH, cV, cD, nr, nc, hlen, f);
+        PDWT_CHECK_LAUNCH();
+        return PDWT_OK;
+    }
+    int rc = launch_ana_rows(in, t1, t2, nr, nc, hlen, f);
+    if (rc != PDWT_OK) return rc;
+    return launch_ana_cols(t1, t2, cA, cH, cV, cD, nr, div2(nc), hlen, f);
+}
+
+// one 2D inverse level: bands (nri x nci) -> out (nro x nco)
+template <typename T>
+static int level_inv2d(const T* cA, const T* cH, const T* cV, const T* cD, T* out, T* t1, T* t2, int nri, int nci, int nro, int nco,
+                       int hlen, const Taps2<T>& f)
+{
+    const size_t lds = inv_fused_lds<T>(hlen);
+    if (lds <= kFusedLdsBudget && !force_twopass()) {
+        dim3 grid(idiv_up(nci, FTX), idiv_up(nri, FTY));
+        KTimer kt(K_INV2D_FUSED);
+        hipLaunchKernelGGL((k_inv2d_fused<T, 0, FTX, FTY>), grid, dim3(kThreads), lds, stream(), cA, cH, cV, cD, out, nri, nci, nro, nco,
+                           hlen, f);
+        PDWT_CHECK_LAUNCH();
+        return PDWT_OK;
+    }
+    int rc = launch_syn_cols(cA, cH, cV, cD, t1, t2, nri, nci, nro, hlen, f);
+    if (rc != PDWT_OK) return rc;
+    return launch_syn_rows(t1, t2, out, nro, nci, nco, hlen, f);
+}
+
+// scratch carving inside d_tmp (>= 2*Nr*Nc + 1024 elements, see pdwt_tmp_elems):
+//   [t1: Nr*Nc2][t2: Nr*Nc2][ping0: Nr2*Nc2][ping1: Nr2*Nc2], each start rounded up to 64 elements
+template <typename T>
+struct Scratch {
+    T *t1, *t2, *ping[2];
+    Scratch(T* tmp, int Nr, int Nc, int ndims)
+    {
+        auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
+        const size_t half = up((size_t)Nr * div2(Nc));
+        const size_t quarter = up((size_t)(ndims == 2 ? div2(Nr) : Nr) * div2(Nc));
+        t1 = tmp;
+        t2 = t1 + half;
+        if (ndims == 2) {
+            ping[0] = t2 + half;
+            ping[1] = ping[0] + quarter;
+        } else {  // 1D: no t1/t2 needed; two half-size ping buffers
+            ping[0] = tmp;
+            ping[1] = tmp + quarter;
+        }
+    }
+};
+
+static int check_args(const void* img, const void* coeffs, const void* tmp, const pdwt_info& w, int ndims, bool need_filters, const void* f,
+                      int fhlen)
+{
+    if (!img || !coeffs || !tmp) return PDWT_EINVAL;
+    if (w.Nr < 1 || w.Nc < 1 || w.nlevels < 1 || w.nlevels > 32) return PDWT_EINVAL;
+    if (w.ndims != ndims) return PDWT_EINVAL;
+    if (need_filters) {
+        if (!f) return PDWT_EINVAL;
+        if (w.hlen < 2 || w.hlen > PDWT_MAX_FILTER_WIDTH || fhlen != w.hlen) return PDWT_EINVAL;
+    }
+    return PDWT_OK;
+}
+
+// ---- drivers ------------------------------------------------------------------------------------
+// w_forward_separable, src/separable.cu:179-209.  The approximation ping-pongs between two scratch
+// buffers (the fused kernel cannot run in place) and lands in band 0 at the last level.
+template <typename T>
+static int forward_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typename FiltersOf<T>::type* filt)
+{
+    int rc = check_args(d_image, c, d_tmp, w, 2, true, filt, filt ? filt->hlen : 0);
+    if (rc != PDWT_OK) return rc;
+    const Taps2<T> f = taps_fwd<T>(filt);
+    Scratch<T> s(d_tmp, w.Nr, w.Nc, 2);
+    const T* in = d_image;
+    int nr = w.Nr, nc = w.Nc;
+    for (int lev = 0; lev < w.nlevels; lev++) {
+        T* aout = (lev == w.nlevels - 1) ? c[0] : s.ping[lev & 1];
+        rc = level_fwd2d(in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], s.t1, s.t2, nr, nc, w.hlen, f);
+        if (rc != PDWT_OK) return rc;
+        in = aout;
+        nr = div2(nr);
+        nc = div2(nc);
+    }
+    return PDWT_OK;
+}
+
+// w_inverse_separable, src/separable.cu:332-364
+template <typename T>
+static int inverse_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typename FiltersOf<T>::type* filt)
+{
+    int rc = check_args(d_image, c, d_tmp, w, 2, true, filt, filt ? filt->hlen : 0);
+    if (rc != PDWT_OK) return rc;
+    const Taps2<T> f = taps_inv<T>(filt);
+    Scratch<T> s(d_tmp, w.Nr, w.Nc, 2);
+    int tNr[34], tNc[34];
+    tNr[0] = w.Nr;
+    tNc[0] = w.Nc;
+    for (int i = 1; i <= w.nlevels; i++) {
+        tNr[i] = div2(tNr[i - 1]);
+        tNc[i] = div2(tNc[i - 1]);
+    }
+    const T* a = c[0];
+    for (int i = w.nlevels - 1; i >= 0; i--) {
+        T* out = (i == 0) ? d_image : s.ping[i & 1];
+        rc = level_inv2d(a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], out, s.t1, s.t2, tNr[i + 1], tNc[i + 1], tNr[i], tNc[i], w.hlen, f);
+        if (rc != PDWT_OK) return rc;
+        a = out;
+    }
+    return PDWT_OK;
+}
+
+// w_forward_separable_1d, src/separable.cu:214-236 (no trailing D2D copy: the last level writes band 0)
+template <typename T>
+static int forward_separable_1d(T* d_image, T** c, T* d_tmp, pdwt_info w, const typename FiltersOf<T>::type* filt)
+{
+    int rc = check_args(d_image, c, d_tmp, w, 1, true, filt, filt ? filt->hlen : 0);
+    if (rc != PDWT_OK) return rc;
+    const Taps2<T> f = taps_fwd<T>(filt);
+    Scratch<T> s(d_tmp, w.Nr, w.Nc, 1);
+    const T* in = d_image;
+    int nc = w.Nc;
+    for (int lev = 0; lev < w.nlevels; lev++) {
+        T* aout = (lev == w.nlevels - 1) ? c[0] : s.ping[lev & 1];
+        rc = launch_ana_rows(in, aout, c[lev + 1], w.Nr, nc, w.hlen, f);
+        if (rc != PDWT_OK) return rc;
+        in = aout;
+        nc = div2(nc);
+    }
+    return PDWT_OK;
+}
+
+// w_inverse_separable_1d, src/separable.cu:368-395
+template <typename T>
+static int inverse_separable_1d(T* d_image, T** c, T* d_tmp, pdwt_info w, const typename FiltersOf<T>::type* filt)
+{
+    int rc = check_args(d_image, c, d_tmp, w, 1, true, filt, filt ? filt->hlen : 0);
+    if (rc != PDWT_OK) return rc;
+    const Taps2<T> f = taps_inv<T>(filt);
+    Scratch<T> s(d_tmp, w.Nr, w.Nc, 1);
+    int tNc[34];
+    tNc[0] = w.Nc;
+    for (int i = 1; i <= w.nlevels; i++) tNc[i] = div2(tNc[i - 1]);
+    const T* a = c[0];
+    for (int i = w.nlevels - 1; i >= 0; i--) {
+        T* out = (i == 0) ? d_image : s.ping[i & 1];
+        rc = launch_syn_rows(a, (const T*)c[i + 1], out, w.Nr, tNc[i + 1], tNc[i], w.hlen, f);
+        if (rc != PDWT_OK) return rc;
+        a = out;
+    }
+    return PDWT_OK;
+}
+
+}  // namespace pdwt
+
+using namespace pdwt;
+
+extern "C" {
+int pdwt_debug_set(const char* key, int value)
+{
+    if (key && !strcmp(key, "force_twopass")) {
+        g_force_twopass = value ? 1 : 0;
+        return PDWT_OK;
+    }
+    return PDWT_EINVAL;
+}
+size_t pdwt_tmp_elems(pdwt_info w) { return 2 * (size_t)(w.Nr > 0 ? w.Nr : 0) * (size_t)(w.Nc > 0 ? w.Nc : 0) + 1024; }
+int pdwt_forward_separable_f32(float* i, float** c, float* t, pdwt_info w, const pdwt_filters_f32* f) { return forward_separable<float>(i, c, t, w, f); }
+int pdwt_forward_separable_f64(double* i, double** c, double* t, pdwt_info w, const pdwt_filters_f64* f) { return forward_separable<double>(i, c, t, w, f); }
+int pdwt_inverse_separable_f32(float* i, float** c, float* t, pdwt_info w, const pdwt_filters_f32* f) { return inverse_separable<float>(i, c, t, w, f); }
+int pdwt_inverse_separable_f64(double* i, double** c, double* t, pdwt_info w, const pdwt_filters_f64* f) { return inverse_separable<double>(i, c, t, w, f); }
+int pdwt_forward_separable_1d_f32(float* i, float** c, float* t, pdwt_info w, const pdwt_filters_f32* f) { return forward_separable_1d<float>(i, c, t, w, f); }
+int pdwt_forward_separable_1d_f64(double* i, double** c, double* t, pdwt_info w, const pdwt_filters_f64* f) { return forward_separable_1d<double>(i, c, t, w, f); }
+int pdwt_inverse_separable_1d_f32(float* i, float** c, float* t, pdwt_info w, const pdwt_filters_f32* f) { return inverse_separable_1d<float>(i, c, t, w, f); }
+int pdwt_inverse_separable_1d_f64(double* i, double** c, double* t, pdwt_info w, const pdwt_filters_f64* f) { return inverse_separable_1d<double>(i, c, t, w, f); }
+}

@@ -1,0 +1,232 @@
+// runtime.hip -- device / memory / stream / event plumbing of the C-ABI (include/pdwt_hip.h).
+// Replaces the bare CUDA runtime calls of the reference's class (src/wt.cu:117-130,421-468,543-549).
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+
+namespace pdwt {
+
+static thread_local char g_err[512] = "";
+
+void set_last_error(hipError_t e, const char* what, const char* file, int line)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s (%s:%d)", hipGetErrorString(e), what, file, line);
+    (void)hipGetLastError();  // clear the sticky error
+}
+
+// one non-blocking stream per device, created on first use
+static std::mutex g_mu;
+static hipStream_t g_streams[64] = {};
+
+hipStream_t stream()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_streams[dev]) {
+        if (hipStreamCreateWithFlags(&g_streams[dev], hipStreamNonBlocking) != hipSuccess) {
+            g_streams[dev] = nullptr;
+        }
+    }
+    return g_streams[dev];
+}
+
+// ---- per-kernel timing ---------------------------------------------------------------------
+static const char* const g_knames[K_COUNT] = {
+    "fwd2d_fused", "inv2d_fused", "ana_rows", "ana_cols", "syn_cols", "syn_rows",
+    "swt_ana_rows", "swt_ana_cols", "swt_syn_cols", "swt_syn_rows",
+    "haar2d_fwd", "haar2d_inv", "haar1d_fwd", "haar1d_inv", "soft_thresh", "abs_sum", "abs_sum_final",
+};
+struct KRec { int id; hipEvent_t e0, e1; };
+static thread_local bool g_kt_on = false;
+static thread_local std::vector<KRec>* g_kt = nullptr;
+static thread_local std::vector<hipEvent_t>* g_evpool = nullptr;
+
+static hipEvent_t ev_get()
+{
+    if (g_evpool && !g_evpool->empty()) {
+        hipEvent_t e = g_evpool->back();
+        g_evpool->pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+KTimer::KTimer(int kernel_id) : id(kernel_id)
+{
+    if (!g_kt_on) return;
+    e0 = ev_get();
+    e1 = ev_get();
+    if (e0) (void)hipEventRecord(e0, stream());
+}
+KTimer::~KTimer()
+{
+    if (!e0 || !e1) return;
+    (void)hipEventRecord(e1, stream());
+    if (!g_kt) g_kt = new std::vector<KRec>();
+    g_kt->push_back(KRec{id, e0, e1});
+}
+
+}  // namespace pdwt
+
+using namespace pdwt;
+
+extern "C" {
+
+int pdwt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+int pdwt_set_device(int dev)
+{
+    PDWT_HIP_TRY(hipSetDevice(dev));
+    return PDWT_OK;
+}
+int pdwt_get_device(void)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return PDWT_EHIP;
+    return dev;
+}
+int pdwt_device_name(char* buf, int buflen)
+{
+    if (!buf || buflen <= 0) return PDWT_EINVAL;
+    int dev = 0;
+    PDWT_HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    PDWT_HIP_TRY(hipGetDeviceProperties(&p, dev));
+    snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return PDWT_OK;
+}
+void* pdwt_malloc(size_t nbytes)
+{
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, nbytes ? nbytes : 1);
+    if (e != hipSuccess) {
+        set_last_error(e, "hipMalloc", __FILE__, __LINE__);
+        return nullptr;
+    }
+    return p;
+}
+int pdwt_free(void* dptr)
+{
+    if (!dptr) return PDWT_OK;
+    PDWT_HIP_TRY(hipStreamSynchronize(stream()));
+    PDWT_HIP_TRY(hipFree(dptr));
+    return PDWT_OK;
+}
+int pdwt_memset(void* dptr, int byte, size_t nbytes)
+{
+    if (!nbytes) return PDWT_OK;
+    PDWT_HIP_TRY(hipMemsetAsync(dptr, byte, nbytes, stream()));
+    return PDWT_OK;
+}
+int pdwt_memcpy_h2d(void* dst, const void* src, size_t nbytes)
+{
+    if (!nbytes) return PDWT_OK;
+    PDWT_HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, stream()));
+    PDWT_HIP_TRY(hipStreamSynchronize(stream()));
+    return PDWT_OK;
+}
+int pdwt_memcpy_d2h(void* dst, const void* src, size_t nbytes)
+{
+    if (!nbytes) return PDWT_OK;
+    PDWT_HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, stream()));
+    PDWT_HIP_TRY(hipStreamSynchronize(stream()));
+    return PDWT_OK;
+}
+int pdwt_memcpy_d2d(void* dst, const void* src, size_t nbytes)
+{
+    if (!nbytes) return PDWT_OK;
+    PDWT_HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, stream()));
+    return PDWT_OK;
+}
+int pdwt_sync(void)
+{
+    PDWT_HIP_TRY(hipStreamSynchronize(stream()));
+    return PDWT_OK;
+}
+void* pdwt_get_stream(void) { return (void*)stream(); }
+const char* pdwt_last_error_string(void) { return g_err; }
+
+void* pdwt_event_create(void)
+{
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return (void*)e;
+}
+int pdwt_event_record(void* ev)
+{
+    PDWT_HIP_TRY(hipEventRecord((hipEvent_t)ev, stream()));
+    return PDWT_OK;
+}
+int pdwt_event_sync(void* ev)
+{
+    PDWT_HIP_TRY(hipEventSynchronize((hipEvent_t)ev));
+    return PDWT_OK;
+}
+float pdwt_event_elapsed_ms(void* a, void* b)
+{
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) return -1.f;
+    return ms;
+}
+int pdwt_event_destroy(void* ev)
+{
+    PDWT_HIP_TRY(hipEventDestroy((hipEvent_t)ev));
+    return PDWT_OK;
+}
+
+int pdwt_ktime_enable(int on)
+{
+    g_kt_on = on != 0;
+    return PDWT_OK;
+}
+int pdwt_ktime_reset(void)
+{
+    if (g_kt) {
+        if (!g_evpool) g_evpool = new std::vector<hipEvent_t>();
+        (void)hipStreamSynchronize(stream());
+        for (auto& r : *g_kt) {
+            g_evpool->push_back(r.e0);
+            g_evpool->push_back(r.e1);
+        }
+        g_kt->clear();
+    }
+    return PDWT_OK;
+}
+int pdwt_ktime_read(int kernel_id, int* n_launches, double* total_ms)
+{
+    if (kernel_id < 0 || kernel_id >= K_COUNT) return PDWT_EINVAL;
+    PDWT_HIP_TRY(hipStreamSynchronize(stream()));
+    int n = 0;
+    double tot = 0;
+    if (g_kt) {
+        for (auto& r : *g_kt) {
+            if (r.id != kernel_id) continue;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+                tot += ms;
+                n++;
+            }
+        }
+    }
+    if (n_launches) *n_launches = n;
+    if (total_ms) *total_ms = tot;
+    return PDWT_OK;
+}
+const char* pdwt_kernel_name(int kernel_id) { return (kernel_id >= 0 && kernel_id < K_COUNT) ? g_knames[kernel_id] : nullptr; }
+int pdwt_kernel_count(void) { return K_COUNT; }
+
+}  // extern "C"

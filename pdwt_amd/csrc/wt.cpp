@@ -1,0 +1,384 @@
+// wt.cpp -- host side of the `Wavelets` class (include/wt.h) above the C-ABI (include/pdwt_hip.h).
+//
+// Mirrors the reference's src/wt.cu: same constructor logic (level clamping src/wt.cu:111-114,
+// 155-165; Nr==1 => 1D :133-136), same variant dispatch (:247-266, :283-301), same state machine
+// (:237-240, :274-281, :311, :476), same band-size arithmetic for get/set_coeff (:441-465,480-504),
+// same memory-footprint report (:527-541).  Plain host C++: compiled by g++, no HIP header, every
+// device action is a C-ABI call into libpdwt_hip.so.  Built twice: libpdwt.so (float) and
+// libpdwtd.so (-DDOUBLEPRECISION), like the reference Makefile:29-39.
+//
+// Deliberate fixes ("F" items): per-instance filters (B-1); unknown wavelet
+// name or a clamp down to 0 levels is a creation error (B-2); return codes of the drivers are
+// checked and mapped onto W_FORWARD_ERROR / W_INVERSE_ERROR / W_THRESHOLD_ERROR (B-10).
+#include <string.h>
+#include <strings.h>
+
+#include "../../include/pdwt_hip.h"
+#include "../../include/wt.h"
+
+static_assert(sizeof(w_info) == sizeof(pdwt_info), "w_info must mirror pdwt_info");
+
+#ifndef DOUBLEPRECISION
+#define SFX(name) name##_f32
+typedef pdwt_filters_f32 filters_t;
+#else
+#define SFX(name) name##_f64
+typedef pdwt_filters_f64 filters_t;
+#endif
+
+// ---- size helpers (reference src/utils.cu:4-34) ------------------------------------------------
+int w_iDivUp(int a, int b) { return (a + b - 1) / b; }
+int w_ipow2(int a) { return 1 << a; }
+int w_ilog2(int i)
+{
+    int l = 0;
+    while (i > 1) {
+        i >>= 1;
+        l++;
+    }
+    return l;
+}
+void w_div2(int* N) { *N = (*N + 1) / 2; }  // ceil-half: odd sizes get one extra element
+void w_swap_ptr(DTYPE** a, DTYPE** b)
+{
+    DTYPE* t = *a;
+    *a = *b;
+    *b = t;
+}
+
+static inline pdwt_info to_pdwt(const w_info& w)
+{
+    pdwt_info p;
+    memcpy(&p, &w, sizeof(p));
+    return p;
+}
+static inline filters_t* F(void* p) { return (filters_t*)p; }
+
+static void report(const char* where, int rc)
+{
+    printf("ERROR: %s failed (code %d): %s\n", where, rc, pdwt_last_error_string());
+}
+
+// ---- constructors / destructor -------------------------------------------------------------------
+Wavelets::Wavelets()
+    : d_image(NULL), d_coeffs(NULL), d_tmp(NULL), current_shift_r(0), current_shift_c(0), do_separable(1), do_cycle_spinning(0),
+      state(W_INIT), filters_(NULL)
+{
+    wname[0] = 0;
+    memset(&winfos, 0, sizeof(winfos));
+}
+
+Wavelets::Wavelets(DTYPE* img, int Nr, int Nc, const char* wname_, int levels, int memisonhost, int do_separable_, int do_cycle_spinning_,
+                   int do_swt, int ndim)
+    : d_image(NULL), d_coeffs(NULL), d_tmp(NULL), current_shift_r(0), current_shift_c(0), do_separable(do_separable_),
+      do_cycle_spinning(do_cycle_spinning_), state(W_INIT), filters_(NULL)
+{
+    winfos.Nr = Nr;
+    winfos.Nc = Nc;
+    winfos.nlevels = levels;
+    winfos.do_swt = do_swt;
+    winfos.ndims = ndim;
+    winfos.hlen = 0;
+    strncpy(this->wname, wname_ ? wname_ : "", 127);
+    this->wname[127] = 0;
+
+    if (Nr < 1 || Nc < 1 || !wname_) {
+        puts("ERROR: Wavelets(): invalid image size or wavelet name");
+        state = W_CREATION_ERROR;
+        return;
+    }
+    if (levels < 1) {
+        puts("Warning: cannot initialize wavelet coefficients with nlevels < 1. Forcing nlevels = 1");
+        winfos.nlevels = 1;
+    }
+    if (Nr == 1) {  // a single row is a 1D signal
+        ndim = 1;
+        winfos.ndims = 1;
+    }
+    if (ndim == 1 && do_separable == 0) {
+        puts("Warning: 1D DWT was requested, which is incompatible with non-separable transform.");
+        puts("Ignoring the do_separable option.");
+        do_separable = 1;
+    }
+    if (!do_separable) {
+        // The non-separable 2D transform (reference src/nonseparable.cu) is outside the hot path this
+        // build replaces; it produces the same coefficients as the separable
+        // one for every bank of the table, so the separable kernels serve the request.
+        puts("Warning: non-separable transform requested; this build computes the (identical) separable transform.");
+        do_separable = 1;
+    }
+    if (ndim != 1 && ndim != 2) {
+        printf("ERROR: ndim=%d is not implemented\n", ndim);
+        state = W_CREATION_ERROR;
+        return;
+    }
+
+    // filters: per-instance copy of the bank
+    filters_t* fb = (filters_t*)calloc(1, sizeof(filters_t));
+    filters_ = fb;
+    int hlen = fb ? SFX(pdwt_compute_filters_separable)(this->wname, do_swt, fb) : 0;
+    if (hlen <= 0) {
+        printf("ERROR: unknown wavelet name %s\n", this->wname);
+        state = W_CREATION_ERROR;
+        return;
+    }
+    winfos.hlen = hlen;
+
+    // maximum level the size allows (== pywt.dwt_max_level), reference src/wt.cu:155-165
+    const int N = (ndim == 2) ? (Nr < Nc ? Nr : Nc) : Nc;
+    const int wmaxlev = w_ilog2(N / (hlen - 1));
+    if (winfos.nlevels > wmaxlev) {
+        printf("Warning: required level (%d) is greater than the maximum possible level for %s (%d) on a %dx%d image.\n", winfos.nlevels,
+               this->wname, wmaxlev, winfos.Nc, winfos.Nr);
+        printf("Forcing nlevels = %d\n", wmaxlev);
+        winfos.nlevels = wmaxlev;
+    }
+    if (winfos.nlevels < 1) {
+        printf("ERROR: a %dx%d image is too small for one level of %s\n", Nc, Nr, this->wname);
+        state = W_CREATION_ERROR;
+        return;
+    }
+    if (do_cycle_spinning && do_swt) puts("Warning: makes little sense to use Cycle spinning with stationary Wavelet transform");
+    if (do_cycle_spinning && ndim == 1) {
+        puts("ERROR: cycle spinning is not implemented for 1D. Use SWT instead.");
+        state = W_CREATION_ERROR;
+        return;
+    }
+
+    // device buffers: image, scratch, bands
+    const size_t nimg = (size_t)Nr * Nc;
+    d_image = (DTYPE*)pdwt_malloc(nimg * sizeof(DTYPE));
+    d_tmp = (DTYPE*)pdwt_malloc(pdwt_tmp_elems(to_pdwt(winfos)) * sizeof(DTYPE));
+    d_coeffs = SFX(pdwt_create_coeffs_buffer)(to_pdwt(winfos));
+    if (!d_image || !d_tmp || !d_coeffs) {
+        printf("ERROR: Wavelets(): device allocation failed: %s\n", pdwt_last_error_string());
+        state = W_CREATION_ERROR;
+        return;
+    }
+    int rc;
+    if (!img) rc = pdwt_memset(d_image, 0, nimg * sizeof(DTYPE));
+    else if (memisonhost) rc = pdwt_memcpy_h2d(d_image, img, nimg * sizeof(DTYPE));
+    else rc = pdwt_memcpy_d2d(d_image, img, nimg * sizeof(DTYPE));
+    if (rc != PDWT_OK) {
+        report("Wavelets(): image upload", rc);
+        state = W_CREATION_ERROR;
+    }
+}
+
+Wavelets::Wavelets(const Wavelets& W)
+    : d_image(NULL), d_coeffs(NULL), d_tmp(NULL), current_shift_r(W.current_shift_r), current_shift_c(W.current_shift_c),
+      do_separable(W.do_separable), do_cycle_spinning(W.do_cycle_spinning), winfos(W.winfos), state(W.state), filters_(NULL)
+{
+    memcpy(wname, W.wname, sizeof(wname));
+    if (W.filters_) {
+        filters_ = malloc(sizeof(filters_t));
+        if (filters_) memcpy(filters_, W.filters_, sizeof(filters_t));
+    }
+    if (!W.d_image || !W.d_coeffs || (winfos.ndims != 1 && winfos.ndims != 2)) {
+        if (winfos.ndims != 1 && winfos.ndims != 2) puts("ERROR: 3D wavelets not implemented yet");
+        state = W_CREATION_ERROR;
+        return;
+    }
+    const size_t nimg = (size_t)winfos.Nr * winfos.Nc;
+    d_image = (DTYPE*)pdwt_malloc(nimg * sizeof(DTYPE));
+    d_tmp = (DTYPE*)pdwt_malloc(pdwt_tmp_elems(to_pdwt(winfos)) * sizeof(DTYPE));
+    d_coeffs = SFX(pdwt_create_coeffs_buffer)(to_pdwt(winfos));
+    if (!d_image || !d_tmp || !d_coeffs || pdwt_memcpy_d2d(d_image, W.d_image, nimg * sizeof(DTYPE)) != PDWT_OK ||
+        SFX(pdwt_copy_coeffs_buffer)(d_coeffs, W.d_coeffs, to_pdwt(winfos)) != PDWT_OK) {
+        printf("ERROR: Wavelets(copy): %s\n", pdwt_last_error_string());
+        state = W_CREATION_ERROR;
+    }
+}
+
+Wavelets::~Wavelets()
+{
+    if (d_image) pdwt_free(d_image);
+    if (d_coeffs) SFX(pdwt_free_coeffs_buffer)(d_coeffs, to_pdwt(winfos));
+    if (d_tmp) pdwt_free(d_tmp);
+    free(filters_);
+}
+
+// ---- transforms ------------------------------------------------------------------------------------
+void Wavelets::forward()
+{
+    if (state == W_CREATION_ERROR) {
+        puts("Warning: forward transform not computed, as there was an error when creating the wavelets");
+        return;
+    }
+    if (do_cycle_spinning) {
+        current_shift_r = rand() % winfos.Nr;
+        current_shift_c = rand() % winfos.Nc;
+        circshift(current_shift_r, current_shift_c, 1);
+    }
+    const pdwt_info w = to_pdwt(winfos);
+    const bool haar = (winfos.hlen == 2) && !winfos.do_swt;  // dedicated 2-tap kernels
+    int rc;
+    if (winfos.ndims == 1) {
+        if (haar) rc = SFX(pdwt_haar_forward1d)(d_image, d_coeffs, d_tmp, w);
+        else if (!winfos.do_swt) rc = SFX(pdwt_forward_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
+        else rc = SFX(pdwt_forward_swt_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
+    } else {
+        if (haar) rc = SFX(pdwt_haar_forward2d)(d_image, d_coeffs, d_tmp, w);
+        else if (!winfos.do_swt) rc = SFX(pdwt_forward_separable)(d_image, d_coeffs, d_tmp, w, F(filters_));
+        else rc = SFX(pdwt_forward_swt_separable)(d_image, d_coeffs, d_tmp, w, F(filters_));
+    }
+    if (rc != PDWT_OK) {
+        report("Wavelets::forward()", rc);
+        state = W_FORWARD_ERROR;
+        return;
+    }
+    state = W_FORWARD;
+}
+
+void Wavelets::inverse()
+{
+    if (state == W_INVERSE) {
+        puts("Warning: W.inverse() has already been run. Inverse is available in W.get_image()");
+        return;
+    }
+    if (state == W_CREATION_ERROR || state == W_FORWARD_ERROR || state == W_THRESHOLD_ERROR) {
+        puts("Warning: inverse transform not computed, as there was an error in a previous stage");
+        return;
+    }
+    const pdwt_info w = to_pdwt(winfos);
+    const bool haar = (winfos.hlen == 2) && !winfos.do_swt;
+    int rc;
+    if (winfos.ndims == 1) {
+        if (haar) rc = SFX(pdwt_haar_inverse1d)(d_image, d_coeffs, d_tmp, w);
+        else if (!winfos.do_swt) rc = SFX(pdwt_inverse_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
+        else rc = SFX(pdwt_inverse_swt_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
+    } else {
+        if (haar) rc = SFX(pdwt_haar_inverse2d)(d_image, d_coeffs, d_tmp, w);
+        else if (!winfos.do_swt) rc = SFX(pdwt_inverse_separable)(d_image, d_coeffs, d_tmp, w, F(filters_));
+        else rc = SFX(pdwt_inverse_swt_separable)(d_image, d_coeffs, d_tmp, w, F(filters_));
+    }
+    if (rc != PDWT_OK) {
+        report("Wavelets::inverse()", rc);
+        state = W_INVERSE_ERROR;
+        return;
+    }
+    if (do_cycle_spinning) circshift(-current_shift_r, -current_shift_c, 1);
+    state = W_INVERSE;
+}
+
+// ---- coefficient utilities -----------------------------------------------------------------------
+void Wavelets::soft_threshold(DTYPE beta, int do_thresh_appcoeffs, int normalize)
+{
+    if (state == W_INVERSE) {
+        puts("Warning: Wavelets(): cannot threshold coefficients, as they were modified by W.inverse()");
+        return;
+    }
+    if (state == W_CREATION_ERROR) return;
+    int rc = SFX(pdwt_soft_thresh)(d_coeffs, beta, to_pdwt(winfos), do_thresh_appcoeffs, normalize);
+    if (rc != PDWT_OK) {
+        report("Wavelets::soft_threshold()", rc);
+        state = W_THRESHOLD_ERROR;
+    }
+}
+
+DTYPE Wavelets::norm1()
+{
+    if (state == W_CREATION_ERROR) return 0;
+    DTYPE res = 0;
+    int rc = SFX(pdwt_norm1)(d_coeffs, to_pdwt(winfos), &res);
+    if (rc != PDWT_OK) report("Wavelets::norm1()", rc);
+    return res;
+}
+
+// The remaining utilities of the reference class are not on the hot path this build replaces
+// (SURVEY.md 8f "next" rows 1-2).  They fail loudly instead of silently doing nothing.
+static void not_built(const char* what)
+{
+    printf("ERROR: Wavelets::%s is not part of this build (hot path only: forward, inverse, soft_threshold, norm1)\n", what);
+}
+void Wavelets::hard_threshold(DTYPE, int, int) { not_built("hard_threshold()"); state = (state == W_INVERSE) ? state : W_THRESHOLD_ERROR; }
+void Wavelets::group_soft_threshold(DTYPE, int, int) { not_built("group_soft_threshold()"); state = (state == W_INVERSE) ? state : W_THRESHOLD_ERROR; }
+void Wavelets::shrink(DTYPE, int) { not_built("shrink()"); state = (state == W_INVERSE) ? state : W_THRESHOLD_ERROR; }
+void Wavelets::proj_linf(DTYPE, int) { not_built("proj_linf()"); state = (state == W_INVERSE) ? state : W_THRESHOLD_ERROR; }
+void Wavelets::circshift(int, int, int) { not_built("circshift()"); }
+DTYPE Wavelets::norm2sq() { not_built("norm2sq()"); return (DTYPE)-1; }
+int Wavelets::set_filters_forward(char*, uint, DTYPE*, DTYPE*, DTYPE*, DTYPE*) { not_built("set_filters_forward()"); return -3; }
+int Wavelets::set_filters_inverse(DTYPE*, DTYPE*, DTYPE*, DTYPE*) { not_built("set_filters_inverse()"); return -3; }
+int Wavelets::add_wavelet(Wavelets, DTYPE) { not_built("add_wavelet()"); return -5; }
+
+// ---- data movement ---------------------------------------------------------------------------------
+int Wavelets::get_image(DTYPE* res)
+{
+    if (!d_image || !res) return 0;
+    const size_t n = (size_t)winfos.Nr * winfos.Nc;
+    if (pdwt_memcpy_d2h(res, d_image, n * sizeof(DTYPE)) != PDWT_OK) return 0;
+    return (int)n;
+}
+
+void Wavelets::set_image(DTYPE* img, int mem_is_on_device)
+{
+    if (!d_image || !img) return;
+    const size_t nb = (size_t)winfos.Nr * winfos.Nc * sizeof(DTYPE);
+    int rc = mem_is_on_device ? pdwt_memcpy_d2d(d_image, img, nb) : pdwt_memcpy_h2d(d_image, img, nb);
+    if (rc != PDWT_OK) report("Wavelets::set_image()", rc);
+    if (state != W_CREATION_ERROR) state = W_INIT;
+}
+
+// band index -> element count.  2D: 0=A, then (H,V,D) per level; 1D: 0=A, then D per level.
+static long long band_elems(const w_info& w, int num)
+{
+    return pdwt_band_size(to_pdwt(w), num, NULL, NULL);
+}
+
+void Wavelets::set_coeff(DTYPE* coeff, int num, int mem_is_on_device)
+{
+    if (!d_coeffs || !coeff) return;
+    const long long n = band_elems(winfos, num);
+    if (n <= 0) {
+        printf("ERROR: set_coeff(): invalid coefficient index %d\n", num);
+        return;
+    }
+    const size_t nb = (size_t)n * sizeof(DTYPE);
+    int rc = mem_is_on_device ? pdwt_memcpy_d2d(d_coeffs[num], coeff, nb) : pdwt_memcpy_h2d(d_coeffs[num], coeff, nb);
+    if (rc != PDWT_OK) report("Wavelets::set_coeff()", rc);
+}
+
+int Wavelets::get_coeff(DTYPE* coeff, int num)
+{
+    if (state == W_INVERSE) {
+        puts("Warning: get_coeff(): inverse() has been performed, the coefficients has been modified and do not make sense anymore.");
+        return 0;
+    }
+    if (!d_coeffs || !coeff) return 0;
+    const long long n = band_elems(winfos, num);
+    if (n <= 0) {
+        printf("ERROR: get_coeff(): invalid coefficient index %d\n", num);
+        return 0;
+    }
+    if (pdwt_memcpy_d2h(coeff, d_coeffs[num], (size_t)n * sizeof(DTYPE)) != PDWT_OK) return 0;
+    return (int)n;
+}
+
+void Wavelets::print_informations()
+{
+    const char* yn[2] = {"no", "yes"};
+    puts("------------- Wavelet transform infos ------------");
+    printf("Data dimensions : ");
+    if (winfos.ndims == 2) printf("(%d, %d)\n", winfos.Nr, winfos.Nc);
+    else if (winfos.Nr == 1) printf("%d\n", winfos.Nc);
+    else printf("(%d, %d) [batched 1D transform]\n", winfos.Nr, winfos.Nc);
+    printf("Wavelet name : %s\n", wname);
+    printf("Number of levels : %d\n", winfos.nlevels);
+    printf("Stationary WT : %s\n", yn[winfos.do_swt ? 1 : 0]);
+    printf("Cycle spinning : %s\n", yn[do_cycle_spinning ? 1 : 0]);
+    printf("Separable transform : %s\n", yn[do_separable ? 1 : 0]);
+    // image (1) + bands + scratch (2); SWT keeps 3L+1 (2D) / L+1 (1D) full-size bands
+    const double n = (double)winfos.Nr * winfos.Nc * sizeof(DTYPE);
+    double mem;
+    if (!winfos.do_swt) mem = 5 * n;
+    else if (winfos.ndims == 2) mem = (3 * winfos.nlevels + 4) * n;
+    else mem = (winfos.nlevels + 4) * n;
+    printf("Estimated memory footprint : %.2f MB\n", mem / 1e6);
+    char name[256] = "unknown";
+    pdwt_device_name(name, (int)sizeof(name));
+    printf("Running on device : %s\n", name);
+    puts("--------------------------------------------------");
+}
+
+intptr_t Wavelets::image_int_ptr(void) { return (intptr_t)d_image; }
+intptr_t Wavelets::coeff_int_ptr(int num) { return (intptr_t)d_coeffs[num]; }

@@ -1,0 +1,38 @@
+// wt_capi.cpp -- flat C handle API over the C++ `Wavelets` class, for FFI callers (ctypes, Cython).
+// This is the shape the reference's external Python binding (pypwt, README.md:24) wraps: one opaque
+// handle per Wavelets instance, methods as functions.  Compiled into libpdwt.so (float) and
+// libpdwtd.so (double) next to wt.cpp; DTYPE follows -DDOUBLEPRECISION.
+#include <new>
+
+#include "../../include/wt.h"
+
+#define W(h) (static_cast<Wavelets*>(h))
+
+extern "C" {
+int pdwt_wavelets_sizeof_dtype(void) { return (int)sizeof(DTYPE); }
+
+void* pdwt_wavelets_new(DTYPE* img, int Nr, int Nc, const char* wname, int levels, int memisonhost, int do_separable, int do_cycle_spinning,
+                        int do_swt, int ndim)
+{
+    return new (std::nothrow) Wavelets(img, Nr, Nc, wname, levels, memisonhost, do_separable, do_cycle_spinning, do_swt, ndim);
+}
+void* pdwt_wavelets_copy(void* h) { return h ? new (std::nothrow) Wavelets(*W(h)) : nullptr; }
+void pdwt_wavelets_delete(void* h) { delete W(h); }
+
+void pdwt_wavelets_forward(void* h) { W(h)->forward(); }
+void pdwt_wavelets_inverse(void* h) { W(h)->inverse(); }
+void pdwt_wavelets_soft_threshold(void* h, DTYPE beta, int do_thresh_appcoeffs, int normalize) { W(h)->soft_threshold(beta, do_thresh_appcoeffs, normalize); }
+DTYPE pdwt_wavelets_norm1(void* h) { return W(h)->norm1(); }
+int pdwt_wavelets_get_image(void* h, DTYPE* out) { return W(h)->get_image(out); }
+void pdwt_wavelets_set_image(void* h, DTYPE* img, int mem_is_on_device) { W(h)->set_image(img, mem_is_on_device); }
+int pdwt_wavelets_get_coeff(void* h, DTYPE* out, int num) { return W(h)->get_coeff(out, num); }
+void pdwt_wavelets_set_coeff(void* h, DTYPE* in, int num, int mem_is_on_device) { W(h)->set_coeff(in, num, mem_is_on_device); }
+void pdwt_wavelets_print_informations(void* h) { W(h)->print_informations(); }
+int pdwt_wavelets_state(void* h) { return (int)W(h)->state; }
+void pdwt_wavelets_set_state(void* h, int s) { W(h)->state = (w_state)s; }
+void pdwt_wavelets_info(void* h, w_info* out) { *out = W(h)->winfos; }
+intptr_t pdwt_wavelets_image_int_ptr(void* h) { return W(h)->image_int_ptr(); }
+intptr_t pdwt_wavelets_coeff_int_ptr(void* h, int num) { return W(h)->coeff_int_ptr(num); }
+intptr_t pdwt_wavelets_coeffs_table_ptr(void* h) { return (intptr_t)W(h)->d_coeffs; }
+intptr_t pdwt_wavelets_tmp_int_ptr(void* h) { return (intptr_t)W(h)->d_tmp; }
+}

@@ -1,0 +1,152 @@
+"""Python view of the C++ ``Wavelets`` class (include/wt.h) through its C handle API.
+
+Method names, argument meaning, defaults and the state machine are the reference's
+(src/wt.h:20-76, src/wt.cu); numpy arrays stand in for the host float*/double* buffers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+W_INIT, W_FORWARD, W_INVERSE, W_THRESHOLD, W_CREATION_ERROR, W_FORWARD_ERROR, W_INVERSE_ERROR, W_THRESHOLD_ERROR = range(8)
+
+
+class Wavelets:
+    def __init__(self, img, wname, levels, do_separable=1, do_cycle_spinning=0, do_swt=0, ndim=2, dtype=None, shape=None, device_ptr=None):
+        """Wavelets(img, Nr, Nc, wname, levels, memisonhost, do_separable, do_cycle_spinning, do_swt, ndim)
+        (src/wt.h:42).  ``img`` is a 2-D (or 1-D) numpy array; or pass ``device_ptr`` + ``shape`` for
+        an image already in HBM (memisonhost=0), or img=None + shape for a zero image."""
+        N.require_gpu()
+        if img is not None:
+            img = np.asarray(img)
+            if dtype is None:
+                dtype = img.dtype if img.dtype in (np.float32, np.float64) else np.float32
+            img = np.ascontiguousarray(img, dtype=dtype)
+            if img.ndim == 1:
+                img = img[None, :]
+            shape = img.shape
+        elif shape is None:
+            raise ValueError("img or shape is required")
+        self.dtype = np.dtype(dtype or np.float32)
+        self.shape = (int(shape[0]), int(shape[1]))
+        self._L = N.host(self.dtype)
+        self._ct = C.c_float if self.dtype == np.float32 else C.c_double
+        if device_ptr is not None:
+            src, on_host = C.c_void_p(int(device_ptr)), 0
+        elif img is not None:
+            src, on_host = img.ctypes.data_as(C.c_void_p), 1
+        else:
+            src, on_host = None, 1
+        self._h = self._L.pdwt_wavelets_new(src, self.shape[0], self.shape[1], wname.encode(), int(levels), on_host, int(do_separable),
+                                            int(do_cycle_spinning), int(do_swt), int(ndim))
+        if not self._h:
+            raise MemoryError("Wavelets allocation failed")
+        self.wname = wname
+
+    @classmethod
+    def _from_handle(cls, other, h):
+        o = cls.__new__(cls)
+        o.dtype, o.shape, o._L, o._ct, o.wname, o._h = other.dtype, other.shape, other._L, other._ct, other.wname, h
+        return o
+
+    def copy(self):  # copy constructor, src/wt.cu:191-222
+        return Wavelets._from_handle(self, self._L.pdwt_wavelets_copy(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pdwt_wavelets_delete(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # -- introspection ---------------------------------------------------------------------
+    @property
+    def info(self):
+        i = N.Info()
+        self._L.pdwt_wavelets_info(self._h, C.byref(i))
+        return i
+
+    @property
+    def state(self):
+        return self._L.pdwt_wavelets_state(self._h)
+
+    @state.setter
+    def state(self, s):
+        self._L.pdwt_wavelets_set_state(self._h, int(s))
+
+    @property
+    def nbands(self):
+        return N.hip().pdwt_num_bands(self.info)
+
+    def band_shape(self, num):
+        r, c = C.c_int(), C.c_int()
+        n = N.hip().pdwt_band_size(self.info, int(num), C.byref(r), C.byref(c))
+        if n <= 0:
+            raise IndexError(num)
+        return r.value, c.value
+
+    # -- the Wavelets API ------------------------------------------------------------------
+    def forward(self):
+        self._L.pdwt_wavelets_forward(self._h)
+
+    def inverse(self):
+        self._L.pdwt_wavelets_inverse(self._h)
+
+    def soft_threshold(self, beta, do_thresh_appcoeffs=0, normalize=0):
+        self._L.pdwt_wavelets_soft_threshold(self._h, self._ct(beta), int(do_thresh_appcoeffs), int(normalize))
+
+    def norm1(self):
+        return self.dtype.type(self._L.pdwt_wavelets_norm1(self._h))
+
+    def norm1_f64(self):
+        """Sum of |c| over all bands, in double (pdwt_norm1_as_double_*): shard-combinable."""
+        out = C.c_double()
+        fn = getattr(N.hip(), "pdwt_norm1_as_double_" + ("f32" if self.dtype == np.float32 else "f64"))
+        P = C.POINTER(C.POINTER(self._ct))
+        rc = fn(C.cast(C.c_void_p(self._L.pdwt_wavelets_coeffs_table_ptr(self._h)), P), self.info, C.byref(out))
+        if rc != 0:
+            raise RuntimeError("pdwt_norm1_as_double failed: %d %s" % (rc, N.hip().pdwt_last_error_string()))
+        return out.value
+
+    def get_image(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        n = self._L.pdwt_wavelets_get_image(self._h, out.ctypes.data_as(C.c_void_p))
+        if n != out.size:
+            raise RuntimeError("get_image failed")
+        return out
+
+    def set_image(self, img, mem_is_on_device=0):
+        if mem_is_on_device:
+            self._L.pdwt_wavelets_set_image(self._h, C.c_void_p(int(img)), 1)
+        else:
+            a = np.ascontiguousarray(img, dtype=self.dtype)
+            assert a.size == self.shape[0] * self.shape[1]
+            self._L.pdwt_wavelets_set_image(self._h, a.ctypes.data_as(C.c_void_p), 0)
+
+    def get_coeff(self, num):
+        r, c = self.band_shape(num)
+        out = np.empty((r, c), dtype=self.dtype)
+        n = self._L.pdwt_wavelets_get_coeff(self._h, out.ctypes.data_as(C.c_void_p), int(num))
+        if n != out.size:
+            raise RuntimeError("get_coeff(%d) failed (state=%d)" % (num, self.state))
+        return out
+
+    def set_coeff(self, arr, num):
+        r, c = self.band_shape(num)
+        a = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert a.size == r * c
+        self._L.pdwt_wavelets_set_coeff(self._h, a.ctypes.data_as(C.c_void_p), int(num), 0)
+
+    @property
+    def coeffs(self):
+        return [self.get_coeff(i) for i in range(self.nbands)]
+
+    def print_informations(self):
+        self._L.pdwt_wavelets_print_informations(self._h)
+
+    def image_int_ptr(self):
+        return self._L.pdwt_wavelets_image_int_ptr(self._h)
+
+    def coeff_int_ptr(self, num):
+        return self._L.pdwt_wavelets_coeff_int_ptr(self._h, int(num))

@@ -1,0 +1,92 @@
+"""CPU-only: the C-ABI libraries load without a GPU and export every symbol include/pdwt_hip.h
+declares; host-side logic that needs no device (filter lookup, band geometry) behaves like the
+reference's."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pdwt_amd
+from pdwt_amd import _native as N
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "pdwt_hip.h")).read()
+    names = set(re.findall(r"\b(pdwt_[a-z0-9_]+)\s*\(", src))
+    # expand the PDWT_DECL_DRIVERS macro: pdwt_xxx_##S
+    macro = set(re.findall(r"\b(pdwt_[a-z0-9_]+)_##S\(", src))
+    out = {n for n in names if not n.endswith("_")}
+    for m in macro:
+        out |= {m + "_f32", m + "_f64"}
+    return out
+
+
+def test_every_declared_symbol_is_exported():
+    L = pdwt_amd.hip()
+    declared = _declared_symbols()
+    assert len(declared) > 60
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    listed = set(N.PLAIN_SYMBOLS) | {"pdwt_%s_%s" % (t, s) for t in N.TYPED_SYMBOLS for s in ("f32", "f64")}
+    assert declared == listed, (declared ^ listed)
+
+
+def test_host_libraries_load_and_report_dtype():
+    assert N.host(np.float32).pdwt_wavelets_sizeof_dtype() == 4
+    assert N.host(np.float64).pdwt_wavelets_sizeof_dtype() == 8
+
+
+def test_filter_lookup_matches_oracle_and_reference_semantics():
+    L = pdwt_amd.hip()
+    assert L.pdwt_num_wavelets() == 72
+    for i in range(72):
+        name = L.pdwt_wavelet_name(i).decode()
+        f = N.Filters64()
+        h = L.pdwt_compute_filters_separable_f64(name.encode(), 0, C.byref(f))
+        ho, taps, _ = orc.filters(name, np.float64)
+        assert h == ho == f.hlen and 2 <= h <= 40 and h % 2 == 0
+        for k in ("L", "H", "IL", "IH"):
+            assert np.array_equal(np.array(getattr(f, k)[:h]), taps[k])
+        f32 = N.Filters32()
+        assert L.pdwt_compute_filters_separable_f32(name.upper().encode(), 1, C.byref(f32)) == h  # case-insensitive
+        assert np.array_equal(np.array(f32.L[:h], dtype=np.float32), taps["L"].astype(np.float32))
+    assert L.pdwt_compute_filters_separable_f32(b"nosuch", 0, None) == -2  # src/separable.cu:42-45
+    for alias in (b"haar", b"db1", b"bior1.1", b"rbior1.1"):
+        assert L.pdwt_compute_filters_separable_f32(alias, 0, None) == 2  # src/separable.cu:24-28
+
+
+@pytest.mark.parametrize("ndims,do_swt", [(2, 0), (1, 0), (2, 1), (1, 1)])
+def test_band_geometry(ndims, do_swt):
+    L = pdwt_amd.hip()
+    for Nr, Nc, lev in ((512, 512, 3), (63, 65, 2), (5, 1000, 4), (4096, 4096, 3)):
+        info = N.Info(ndims, Nr, Nc, lev, do_swt, 8)
+        shapes = orc.band_shapes(Nr, Nc, lev, do_swt, ndims)
+        assert L.pdwt_num_bands(info) == len(shapes)
+        for k, (r, c) in enumerate(shapes):
+            br, bc = C.c_int(), C.c_int()
+            assert L.pdwt_band_size(info, k, C.byref(br), C.byref(bc)) == r * c
+            assert (br.value, bc.value) == (r, c)
+    assert L.pdwt_band_size(N.Info(2, 8, 8, 1, 0, 2), 4, None, None) < 0
+    assert L.pdwt_tmp_elems(N.Info(2, 100, 50, 1, 0, 2)) >= 2 * 100 * 50
+
+
+def test_product_fails_loudly_without_gpu():
+    if pdwt_amd.hip().pdwt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        pdwt_amd.Wavelets(np.zeros((8, 8), np.float32), "db2", 1)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under pdwt_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "pdwt_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "libpdwt_oracle" not in txt and "orc_" not in txt, f

@@ -1,0 +1,304 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI / the C++ Wavelets class) against
+  (1) the committed PyWavelets golden vectors, (2) the CPU oracle on the same seeded inputs,
+  (3) size-independent properties at BASELINE.json's full sizes.
+Tolerances (band-normalised max error, tests/helpers.py): 1e-5 for float32 (BASELINE.json
+north_star), 1e-10 for float64; bit-exact for the Haar path (integer indexing, exact butterflies).
+"""
+import numpy as np
+import pytest
+
+import pdwt_amd
+from oracle import oracle as orc
+from tests.helpers import GOLDEN, GOLDEN_CASES, KIND, TOL, band_err, golden_bands, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(x, wname, levels, **kw):
+    """(HIP Wavelets, oracle Wavelets) on the same input."""
+    W = pdwt_amd.Wavelets(x, wname, levels, do_swt=kw.get("do_swt", 0), ndim=kw.get("ndim", 2))
+    O = orc.OracleWavelets(x, wname, levels, do_swt=kw.get("do_swt", 0), ndim=kw.get("ndim", 2))
+    i, j = W.info, O.info
+    assert (i.ndims, i.Nr, i.Nc, i.nlevels, i.do_swt, i.hlen) == (j.ndims, j.Nr, j.Nc, j.nlevels, j.do_swt, j.hlen)
+    return W, O
+
+
+def _check_against_oracle(x, wname, levels, tol=None, exact=False, **kw):
+    W, O = _pair(x, wname, levels, **kw)
+    tol = TOL[np.dtype(x.dtype)] if tol is None else tol
+    W.forward()
+    O.forward()
+    assert W.state == pdwt_amd.W_FORWARD
+    gc, oc = W.coeffs, O.coeffs
+    assert len(gc) == len(oc)
+    for k, (g, o) in enumerate(zip(gc, oc)):
+        if exact:
+            assert np.array_equal(g, o), (wname, "band", k)
+        else:
+            assert band_err(g, o) <= tol, (wname, x.shape, "band", k, band_err(g, o))
+    assert np.array_equal(W.get_image(), x), "forward() must leave the image intact"
+    W.inverse()
+    O.inverse()
+    assert W.state == pdwt_amd.W_INVERSE
+    gi, oi = W.get_image(), O.get_image()
+    if exact:
+        assert np.array_equal(gi, oi)
+    else:
+        assert band_err(gi, oi) <= tol, (wname, x.shape, "inverse", band_err(gi, oi))
+    return W, O
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_golden_vectors(name):
+    d = load_golden(name)
+    x = d["input"]
+    W = pdwt_amd.Wavelets(x, d["wname"], d["levels"], **KIND[d["kind"]])
+    assert W.info.nlevels == d["levels"]
+    W.forward()
+    tol = TOL[x.dtype]
+    for k, (g, e) in enumerate(zip(W.coeffs, golden_bands(d))):
+        assert band_err(g, e) <= tol, (name, "band", k, band_err(g, e))
+    # demo.cpp:208-218: zero the image, invert from the coefficients
+    W.set_image(np.zeros_like(x))
+    W.state = pdwt_amd.W_FORWARD
+    W.inverse()
+    assert band_err(W.get_image(), d["recon"]) <= tol
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_golden_inputs_vs_oracle(name):
+    d = load_golden(name)
+    haar = d["wname"] == "haar" and d["kind"] in ("dwt2", "dwt1")
+    _check_against_oracle(d["input"], d["wname"], d["levels"], exact=haar, **KIND[d["kind"]])
+
+
+def test_config1_lena_haar_bit_exact():
+    """BASELINE.json configs[0]: 512x512 lena.dat, haar, 1 level.  Integer-valued input: the 2x2
+    butterfly is exact in float32 -> HIP == oracle bit for bit, perfect reconstruction."""
+    lena = np.fromfile(GOLDEN + "/lena.dat", dtype=np.float32).reshape(512, 512)
+    W, O = _check_against_oracle(lena, "haar", 1, exact=True)
+    assert np.array_equal(W.get_image(), lena)
+    d = load_golden("lena512_haar_L1_summary")
+    W2 = pdwt_amd.Wavelets(lena, "haar", 1)
+    W2.forward()
+    for i, b in enumerate(W2.coeffs):
+        assert band_err(b[::16, ::16], d["sample"][i]) <= 1e-5
+
+
+@pytest.mark.parametrize("levels", [1, 2, 3, 5])
+def test_haar_multilevel_bit_exact(levels):
+    rs = np.random.RandomState(levels)
+    for shape in ((64, 64), (37, 51), (128, 36), (33, 33)):
+        for dt in (np.float32, np.float64):
+            _check_against_oracle(rs.uniform(-50, 50, shape).astype(dt), "haar", levels, exact=True)
+    for shape in ((3, 77), (1, 64), (8, 130)):
+        for dt in (np.float32, np.float64):
+            _check_against_oracle(rs.uniform(-50, 50, shape).astype(dt), "haar", levels, exact=True, ndim=1)
+
+
+SHAPES_2D = [(64, 64), (128, 192), (63, 65), (31, 40), (50, 37), (200, 72), (129, 257), (512, 512)]
+WAVELETS = ["db2", "db3", "db4", "db7", "sym8", "coif2", "bior2.4", "rbio3.3", "db10", "db20", "sym13"]
+
+
+@pytest.mark.parametrize("wname", WAVELETS)
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_dwt2_vs_oracle(wname, dt):
+    rs = np.random.RandomState(abs(hash(wname)) % 1000)
+    for shape in SHAPES_2D:
+        x = rs.uniform(0, 255, shape).astype(dt)
+        for levels in (1, 3):
+            _check_against_oracle(x, wname, levels)
+
+
+@pytest.mark.parametrize("wname", ["db4", "db7", "sym8", "db20"])
+def test_dwt2_fused_equals_twopass(wname):
+    """The fused level kernel and the two-pass (row kernel + column kernel) form are the same
+    arithmetic in the same order -> bit-identical."""
+    rs = np.random.RandomState(11)
+    L = pdwt_amd.hip()
+    for shape in ((256, 320), (97, 131)):
+        x = rs.randn(*shape).astype(np.float32)
+        res = []
+        for force in (0, 1):
+            assert L.pdwt_debug_set(b"force_twopass", force) == 0
+            try:
+                W = pdwt_amd.Wavelets(x, wname, 2)
+                W.forward()
+                c = W.coeffs
+                W.inverse()
+                res.append((c, W.get_image()))
+            finally:
+                L.pdwt_debug_set(b"force_twopass", 0)
+        for a, b in zip(res[0][0], res[1][0]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("wname", ["db2", "db5", "sym8", "db20", "bior3.5"])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_batched_1d_vs_oracle(wname, dt):
+    rs = np.random.RandomState(7)
+    for shape in ((5, 256), (3, 77), (1, 1000), (17, 513), (64, 2048)):
+        x = rs.randn(*shape).astype(dt)
+        for levels in (1, 4):
+            _check_against_oracle(x, wname, levels, ndim=1)
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db7", "sym4"])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_swt_vs_oracle(wname, dt):
+    rs = np.random.RandomState(9)
+    for shape in ((64, 64), (48, 80), (112, 112), (50, 70)):  # PDWT's SWT does not need 2^L-divisible sizes
+        x = rs.uniform(0, 255, shape).astype(dt)
+        for levels in (1, 3):
+            _check_against_oracle(x, wname, levels, do_swt=1)
+    for shape in ((6, 128), (1, 300)):
+        x = rs.randn(*shape).astype(dt)
+        _check_against_oracle(x, wname, 3, do_swt=1, ndim=1)
+
+
+def test_all_72_wavelets_1d():
+    d = load_golden("all72_1d_2x256_L1")
+    x = d["input"]
+    for n in [str(s) for s in d["names"]]:
+        W = pdwt_amd.Wavelets(x, n, 1, ndim=1)
+        W.forward()
+        A, D = W.coeffs
+        assert band_err(A, d["A_" + n]) <= 1e-10, n
+        assert band_err(D, d["D_" + n]) <= 1e-10, n
+        W.inverse()
+        assert band_err(W.get_image(), x) <= 1e-9, n
+
+
+def test_soft_threshold_and_norm1_vs_oracle():
+    rs = np.random.RandomState(21)
+    for dt, tol in ((np.float32, 1e-6), (np.float64, 1e-12)):
+        for kw in (dict(), dict(ndim=1), dict(do_swt=1)):
+            x = rs.randn(96, 160).astype(dt) * 10
+            W, O = _pair(x, "db3", 3, **kw)
+            W.forward()
+            O.forward()
+            assert abs(W.norm1_f64() - O.norm1_f64()) <= tol * O.norm1_f64()
+            assert abs(float(W.norm1()) - float(O.norm1())) <= 2e-6 * float(O.norm1())
+            for app, norm in ((0, 0), (1, 0), (1, 1), (0, 2)):
+                W.soft_threshold(0.7, app, norm)
+                O.soft_threshold(0.7, app, norm)
+                for g, o in zip(W.coeffs, O.coeffs):
+                    assert band_err(g, o) <= TOL[np.dtype(dt)]
+                assert abs(W.norm1_f64() - O.norm1_f64()) <= max(tol, 1e-6 if dt == np.float32 else tol) * O.norm1_f64()
+
+
+def test_pipeline_db20_f64_golden():
+    """Config C5 in miniature against the PyWavelets pipeline fixture."""
+    d = load_golden("pipe160x192_db20_L2_f64")
+    W = pdwt_amd.Wavelets(d["input"], "db20", 2)
+    W.forward()
+    for g, e in zip(W.coeffs, golden_bands(d)):
+        assert band_err(g, e) <= 1e-10
+    assert abs(W.norm1_f64() - float(d["norm1_before"])) <= 1e-10 * float(d["norm1_before"])
+    W.soft_threshold(float(d["beta"]))
+    assert abs(W.norm1_f64() - float(d["norm1_after"])) <= 1e-10 * float(d["norm1_after"])
+    W.inverse()
+    assert band_err(W.get_image(), d["recon_thresh"]) <= 1e-10
+
+
+def test_state_machine_and_errors():
+    x = np.random.RandomState(0).randn(64, 64).astype(np.float32)
+    W = pdwt_amd.Wavelets(x, "db4", 10)
+    assert W.info.nlevels == 3  # clamped: ilog2(64/7), src/wt.cu:155-165
+    assert pdwt_amd.Wavelets(x, "db4", 0).info.nlevels == 1
+    W.forward()
+    W.inverse()
+    img = W.get_image()
+    W.inverse()  # second inverse is a no-op (src/wt.cu:274-277)
+    assert np.array_equal(W.get_image(), img)
+    with pytest.raises(RuntimeError):
+        W.get_coeff(0)  # coefficients are gone after inverse (src/wt.cu:476-479)
+    W.forward()  # always allowed, resets the state
+    assert W.state == pdwt_amd.W_FORWARD
+    bad = pdwt_amd.Wavelets(x, "nosuchwavelet", 2)
+    assert bad.state == pdwt_amd.W_CREATION_ERROR
+    bad.forward()
+    assert bad.state == pdwt_amd.W_CREATION_ERROR
+    # two live instances keep their own filters (SURVEY B-1)
+    A = pdwt_amd.Wavelets(x, "db2", 1)
+    B = pdwt_amd.Wavelets(x, "db7", 1)
+    A.forward()
+    O = orc.OracleWavelets(x, "db2", 1)
+    O.forward()
+    assert band_err(A.get_coeff(1), O.get_coeff(1)) <= 1e-6
+    # copy constructor deep-copies image + coefficients
+    Cp = A.copy()
+    assert np.array_equal(Cp.get_coeff(2), A.get_coeff(2))
+    del B
+
+
+def test_config2_full_size_4096_db4_L3():
+    """BASELINE.json configs[1] at full size: HIP vs oracle on every band, round trip, and linearity."""
+    rs = np.random.RandomState(0)
+    x = rs.uniform(0, 255, (4096, 4096)).astype(np.float32)
+    W, O = _check_against_oracle(x, "db4", 3)
+    assert band_err(W.get_image(), x) <= 1e-5  # perfect reconstruction (orthogonal bank)
+    # linearity: T(a*x + y) == a*T(x) + T(y) on the approximation band
+    y = rs.uniform(0, 255, (4096, 4096)).astype(np.float32)
+    Wy = pdwt_amd.Wavelets(y, "db4", 3)
+    Wy.forward()
+    Wxy = pdwt_amd.Wavelets((0.5 * x + y).astype(np.float32), "db4", 3)
+    Wxy.forward()
+    Wx = pdwt_amd.Wavelets(x, "db4", 3)
+    Wx.forward()
+    assert band_err(Wxy.get_coeff(0), 0.5 * Wx.get_coeff(0).astype(np.float64) + Wy.get_coeff(0)) <= 1e-5
+    # energy conservation of an orthogonal transform (Parseval), in double
+    e_in = float((x.astype(np.float64) ** 2).sum())
+    e_out = sum(float((b.astype(np.float64) ** 2).sum()) for b in Wx.coeffs)
+    assert abs(e_in - e_out) <= 1e-5 * e_in
+
+
+def test_config3_swt_db7_L5_reduced_and_full_roundtrip():
+    """configs[2]: db7 SWT 5 levels.  Oracle parity at 1024^2 (the oracle needs ~10 s there),
+    round-trip property at the full 4096^2."""
+    rs = np.random.RandomState(3)
+    x = rs.uniform(0, 255, (1024, 1024)).astype(np.float32)
+    _check_against_oracle(x, "db7", 5, do_swt=1)
+    x = rs.uniform(0, 255, (4096, 4096)).astype(np.float32)
+    W = pdwt_amd.Wavelets(x, "db7", 5, do_swt=1)
+    assert W.info.nlevels == 5
+    W.forward()
+    W.set_image(np.zeros_like(x))
+    W.state = pdwt_amd.W_FORWARD
+    W.inverse()
+    assert band_err(W.get_image(), x) <= 1e-5
+
+
+def test_config4_batched_1d_shard_sym8_L4():
+    """configs[3], one GPU's shard of the 8-way split: 8192 x 8192 float32 sym8 4 levels."""
+    rs = np.random.RandomState(1)
+    x = rs.randn(8192, 8192).astype(np.float32)
+    W = pdwt_amd.Wavelets(x, "sym8", 4, ndim=1)
+    W.forward()
+    # oracle on a row subset (rows are independent signals)
+    rows = np.r_[0:4, 4093:4099, 8188:8192]
+    O = orc.OracleWavelets(x[rows], "sym8", 4, ndim=1)
+    O.forward()
+    for k in range(5):
+        assert band_err(W.get_coeff(k)[rows], O.get_coeff(k)) <= 1e-5
+    W.inverse()
+    assert band_err(W.get_image(), x) <= 1e-5
+
+
+def test_config5_f64_db20_L6_threshold_norm1_reduced():
+    """configs[4] at 2048^2 (oracle-sized): f64 db20, clamp to the max level, threshold + norm1."""
+    rs = np.random.RandomState(2)
+    x = rs.randn(2048, 2048)
+    W, O = _pair(x, "db20", 6)
+    assert W.info.nlevels == 5  # ilog2(2048/39)
+    W.forward()
+    O.forward()
+    for g, o in zip(W.coeffs, O.coeffs):
+        assert band_err(g, o) <= 1e-10
+    W.soft_threshold(0.5)
+    O.soft_threshold(0.5)
+    assert abs(W.norm1_f64() - O.norm1_f64()) <= 1e-10 * O.norm1_f64()
+    W.inverse()
+    O.inverse()
+    assert band_err(W.get_image(), O.get_image()) <= 1e-10
