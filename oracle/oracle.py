@@ -48,6 +48,9 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.orc_norm1_f32.restype = C.c_double
         _LIB.orc_norm1_f64.restype = C.c_double
+        # parity tests run many small problems: a 256-thread OpenMP team per loop is pure overhead.
+        # bench.py's cpu_baseline leg raises this to all cores explicitly.
+        _LIB.orc_set_num_threads(min(16, os.cpu_count() or 1))
     return _LIB
 
 

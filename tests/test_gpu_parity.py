@@ -23,7 +23,18 @@ def _pair(x, wname, levels, **kw):
     return W, O
 
 
+def _fits(shape, wname, ndim=2):
+    """False when the image is too small for even one level (src/wt.cu:159 clamps to 0 levels)."""
+    hlen = orc.filters(wname)[0]
+    n = min(shape) if ndim == 2 and shape[0] > 1 else shape[1]
+    return orc.ilog2(n // (hlen - 1)) >= 1
+
+
 def _check_against_oracle(x, wname, levels, tol=None, exact=False, **kw):
+    if not _fits(x.shape, wname, kw.get("ndim", 2)):
+        W = pdwt_amd.Wavelets(x, wname, levels, do_swt=kw.get("do_swt", 0), ndim=kw.get("ndim", 2))
+        assert W.state == pdwt_amd.W_CREATION_ERROR  # SURVEY B-2: 0 levels is a creation error here
+        return None, None
     W, O = _pair(x, wname, levels, **kw)
     tol = TOL[np.dtype(x.dtype)] if tol is None else tol
     W.forward()
