@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the PDWT hot path on MI355X.
+
+Metric (BASELINE.json): Mpixels/s of one forward()+inverse() pair of the separable DWT,
+4096x4096 float32, db4, 3 levels (configs[1]), inputs resident in HBM when the timed region starts,
+plus the achieved HBM GB/s of the dominant kernel against the chip's 8 TB/s peak.
+
+A "step" = one Wavelets.forward() + Wavelets.inverse() on one image per GPU.  N > 1 (launched by
+torch.distributed.run, one rank per GPU) is the batch split of BASELINE.json: whole images are
+independent, so every rank transforms its own image -- no data-path collective -- and the job
+throughput is N images per step ("scaling": "weak").  RCCL is used only for the barriers and the
+max-over-ranks of the elapsed time.
+
+Extra objects in the JSON line:
+  roofline      dominant kernel: algorithmic bytes of its launches / their HIP-event duration
+                (events recorded on the library stream by pdwt_ktime_*), vs 8000 GB/s.
+  cpu_baseline  the CPU oracle (plain-C restatement, OpenMP) timed on this host's cores on a
+                bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+
+# name -> (rows per GPU, cols, dtype, wavelet, levels, do_swt, ndim, extra ops, unit)
+CONFIGS = {
+    "c2": dict(Nr=4096, Nc=4096, dtype="float32", wname="db4", levels=3, do_swt=0, ndim=2, extra=False, unit="Mpixels/s",
+               desc="4096x4096 float32, db4, 3 levels, separable DWT fwd+inv (BASELINE.json configs[1])"),
+    "c3": dict(Nr=4096, Nc=4096, dtype="float32", wname="db7", levels=5, do_swt=1, ndim=2, extra=False, unit="Mpixels/s",
+               desc="4096x4096 float32, db7, 5 levels, SWT fwd+inv (configs[2])"),
+    "c4": dict(Nr=8192, Nc=8192, dtype="float32", wname="sym8", levels=4, do_swt=0, ndim=1, extra=False, unit="Msamples/s",
+               desc="batched-1D shard: 8192 signals x 8192 samples per GPU (65536 over 8 GPUs), sym8, 4 levels (configs[3])"),
+    "c5": dict(Nr=8192, Nc=8192, dtype="float64", wname="db20", levels=6, do_swt=0, ndim=2, extra=True, unit="Mpixels/s",
+               desc="8192x8192 float64, db20, 6 levels + soft_threshold + norm1 (configs[4])"),
+}
+
+
+def algorithmic_bytes(cfg, levels_eff):
+    """Per-step ALGORITHMIC (compulsory) bytes, SURVEY.md 8(d), and per-kernel-launch-set figures.
+
+    whole step : DWT fwd+inv = 4*N*sizeof(T); SWT-2D = 2*(3L+2)*N*sizeof(T); SWT-1D = 2*(L+2)*N*sizeof
+    per kernel : each level kernel must read its inputs once and write its outputs once:
+                 fused 2D DWT level on an n-element input: (n + 4*n/4)*sizeof = 2*n*sizeof, both directions;
+                 1-D level: 2*n*sizeof; SWT pass kernels: rows (1 in, 2 out), cols (2 in, 4 out), ...
+    """
+    import numpy as np
+    sz = np.dtype(cfg["dtype"]).itemsize
+    N = cfg["Nr"] * cfg["Nc"]
+    L = levels_eff
+    per_kernel = {}
+    if cfg["do_swt"]:
+        if cfg["ndim"] == 2:
+            step = 2 * (3 * L + 2) * N * sz
+            per_kernel = {"swt_ana_rows": 3 * N * sz * L, "swt_ana_cols": 6 * N * sz * L, "swt_syn_cols": 6 * N * sz * L, "swt_syn_rows": 3 * N * sz * L}
+        else:
+            step = 2 * (L + 2) * N * sz
+            per_kernel = {"swt_ana_rows": 3 * N * sz * L, "swt_syn_rows": 3 * N * sz * L}
+    else:
+        step = 4 * N * sz
+        n = 0
+        r, c = cfg["Nr"], cfg["Nc"]
+        for _ in range(L):
+            n += r * c
+            if cfg["ndim"] == 2:
+                r = (r + 1) // 2
+            c = (c + 1) // 2
+        if cfg["ndim"] == 2:
+            per_kernel = {"fwd2d_fused": 2 * n * sz, "inv2d_fused": 2 * n * sz,
+                          "ana_rows": 2 * n * sz, "ana_cols": 2 * n * sz, "syn_cols": 2 * n * sz, "syn_rows": 2 * n * sz,
+                          "haar2d_fwd": 2 * n * sz, "haar2d_inv": 2 * n * sz}
+        else:
+            per_kernel = {"ana_rows": 2 * n * sz, "syn_rows": 2 * n * sz, "haar1d_fwd": 2 * n * sz, "haar1d_inv": 2 * n * sz}
+    return step, per_kernel
+
+
+def cpu_baseline(cfg, seconds_budget):
+    """Time the CPU oracle (kind 'port') on this host's cores on a bounded sample of the workload."""
+    import numpy as np
+    from oracle import oracle as orc
+    Nr, Nc = cfg["Nr"], cfg["Nc"]
+    scale = 1
+    # keep one pair at a few seconds at most: shrink the sample for the heavy configs
+    while cfg["do_swt"] and Nr * Nc > 1024 * 1024:
+        Nr //= 2
+        Nc //= 2
+        scale *= 4
+    if cfg["dtype"] == "float64" and Nr * Nc > 4096 * 4096:
+        Nr //= 2
+        Nc //= 2
+        scale *= 4
+    rs = np.random.RandomState(0)
+    x = rs.uniform(0, 255, (Nr, Nc)).astype(cfg["dtype"])
+    W = orc.OracleWavelets(x, cfg["wname"], cfg["levels"], do_swt=cfg["do_swt"], ndim=cfg["ndim"])
+
+    def pair():
+        W.forward()
+        if cfg["extra"]:
+            W.soft_threshold(0.5)
+            W.norm1_f64()
+        W.inverse()
+
+    ncores = os.cpu_count() or 1
+    res = {}
+    for label, nthreads in (("single", 1), ("all", ncores)):
+        used = orc.set_num_threads(nthreads)
+        pair()  # warm (page faults, thread team)
+        t0 = time.perf_counter()
+        pair()
+        t1 = time.perf_counter() - t0
+        budget = seconds_budget * (0.3 if label == "single" else 0.7)
+        reps = int(max(1, min(200, budget / max(t1, 1e-6))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pair()
+        dt = (time.perf_counter() - t0) / reps
+        res[label] = dict(value=Nr * Nc / dt / 1e6, threads=used, reps=reps, s_per_pair=dt)
+    best = max(res.values(), key=lambda r: r["value"])
+    return {
+        "value": round(best["value"], 2), "unit": cfg["unit"], "cores": best["threads"], "kind": "port",
+        "sample": "%d x fwd+inv of a %dx%d %s %s L%d input (%s of the GPU workload's pixels per pair), oracle/pdwt_oracle.c with OpenMP" % (
+            best["reps"], Nr, Nc, cfg["dtype"], cfg["wname"], W.info.nlevels, "all" if scale == 1 else "1/%d" % scale),
+        "single_thread_value": round(res["single"]["value"], 2), "host_cores": ncores,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    # torch first: its bundled ROCm runtime then also serves libpdwt_hip.so (one HIP runtime per process)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import pdwt_amd
+
+    cfg = CONFIGS[args.config]
+    torch.cuda.set_device(local_rank)
+    L = pdwt_amd.hip()
+    assert L.pdwt_set_device(local_rank) == 0
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # synthetic input generated on the GPU that owns it (uniform [0,255), seed = rank)
+    tdt = torch.float32 if cfg["dtype"] == "float32" else torch.float64
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234 + rank)
+    img = torch.rand(cfg["Nr"], cfg["Nc"], device="cuda", dtype=tdt, generator=g) * 255.0
+    torch.cuda.synchronize()
+    W = pdwt_amd.Wavelets(None, cfg["wname"], cfg["levels"], do_swt=cfg["do_swt"], ndim=cfg["ndim"], dtype=cfg["dtype"],
+                          shape=(cfg["Nr"], cfg["Nc"]), device_ptr=img.data_ptr())
+    assert W.state == pdwt_amd.W_INIT, "Wavelets creation failed"
+    levels_eff = W.info.nlevels
+
+    if cfg["extra"]:
+        def step():
+            W.forward()
+            W.soft_threshold(0.5)
+            W.norm1()
+            W.inverse()
+    else:
+        def step():
+            W.forward()
+            W.inverse()
+
+    def sync():
+        L.pdwt_sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    barrier()
+    sync()
+    e0, e1 = L.pdwt_event_create(), L.pdwt_event_create()
+    t0 = time.perf_counter()
+    L.pdwt_event_record(e0)
+    for _ in range(args.steps):
+        step()
+    L.pdwt_event_record(e1)
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    gpu_ms = L.pdwt_event_elapsed_ms(e0, e1)
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity of the timed work: the round trip reproduces the input (pixels really went through)
+    rt_err = None
+    if not cfg["extra"]:
+        out = W.get_image()
+        ref = img.cpu().numpy()
+        rt_err = float(np.abs(out.astype(np.float64) - ref).max() / np.abs(ref).max())
+
+    pixels = cfg["Nr"] * cfg["Nc"]
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * pixels / (elapsed / args.steps) / 1e6
+    step_bytes, per_kernel_bytes = algorithmic_bytes(cfg, levels_eff)
+
+    roofline = None
+    kernels = {}
+    if not args.no_roofline:
+        L.pdwt_ktime_enable(1)
+        L.pdwt_ktime_reset()
+        ksteps = min(args.steps, 50)
+        for _ in range(ksteps):
+            step()
+        sync()
+        n, ms = C.c_int(), C.c_double()
+        for k in range(L.pdwt_kernel_count()):
+            L.pdwt_ktime_read(k, C.byref(n), C.byref(ms))
+            if n.value:
+                kernels[L.pdwt_kernel_name(k).decode()] = dict(launches_per_step=n.value / ksteps, us_per_step=ms.value * 1e3 / ksteps,
+                                                               avg_us=ms.value * 1e3 / n.value)
+        L.pdwt_ktime_enable(0)
+        L.pdwt_ktime_reset()
+        cand = [k for k in kernels if k in per_kernel_bytes]
+        if cand:
+            dom = max(cand, key=lambda k: kernels[k]["us_per_step"])
+            kb = per_kernel_bytes[dom]
+            ach = kb / (kernels[dom]["us_per_step"] * 1e-6) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": kb / kernels[dom]["launches_per_step"],
+                        "avg_launch_us": round(kernels[dom]["avg_us"], 2), "launches_per_step": kernels[dom]["launches_per_step"],
+                        "step_compulsory_bytes": step_bytes,
+                        "step_compulsory_GBps": round(step_bytes / (gpu_ms / args.steps * 1e-3) / 1e9, 1),
+                        "step_frac_of_peak": round(step_bytes / (gpu_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baseline(cfg, args.cpu_seconds)
+
+    if rank == 0:
+        line = {
+            "metric": "Mpixels/s fwd+inv DWT (4096^2 db4 L3)" if args.config == "c2" else "%s fwd+inv (%s)" % (cfg["unit"], args.config),
+            "value": round(value, 1), "unit": cfg["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if cfg["dtype"] == "float32" else "f64", "data": "synthetic",
+            "config": {"workload": cfg["desc"], "images_per_gpu_per_step": 1, "levels": levels_eff, "parallelism": "batch-split x%d (no data-path collective)" % world},
+            "gpu_ms_per_step": round(gpu_ms / args.steps, 5), "roundtrip_max_rel_err": rt_err,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": {k: {a: round(b, 3) for a, b in v.items()} for k, v in kernels.items()},
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,9 +19,9 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib")
 INC = os.path.join(ROOT, "include")
 
-HIP_SOURCES = ["runtime.hip", "coeffs.hip", "dwt.hip", "swt.hip", "haar.hip", "utils.hip", "filters.cpp"]
+HIP_SOURCES = ["runtime.hip", "coeffs.hip", "dwt.hip", "dwt_stream.hip", "swt.hip", "haar.hip", "utils.hip", "filters.cpp"]
 HOST_SOURCES = ["wt.cpp", "wt_capi.cpp"]
-HIP_DEPS = ["common.hpp", "filters_table.inc"]
+HIP_DEPS = ["common.hpp", "dwt_stream.hpp", "filters_table.inc"]
 ARCH = "gfx950"
 
 
@@ -50,7 +50,8 @@ def build_hip(force=False):
     deps = srcs + [os.path.join(CSRC, d) for d in HIP_DEPS] + [os.path.join(INC, "pdwt_hip.h")]
     if force or _newer(deps, out):
         os.makedirs(LIB, exist_ok=True)
-        _run([hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", out] + srcs)
+        extra = os.environ.get("PDWT_HIPCC_FLAGS", "").split()
+        _run([hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall"] + extra + ["-o", out] + srcs)
     return out
 
 

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "common.hpp"
+#include "dwt_stream.hpp"
 
 namespace pdwt {
 
@@ -490,6 +491,12 @@ static int launch_syn_cols(const T* cA, const T* cH, const T* cV, const T* cD, T
 template <typename T>
 static int level_fwd2d(const T* in, T* cA, T* cH, T* cV, T* cD, T* t1, T* t2, int nr, int nc, int hlen, const Taps2<T>& f)
 {
+    if constexpr (sizeof(T) == 4) {  // float32 fast path: LDS-free streaming kernel (dwt_stream.hip)
+        if (!force_twopass()) {
+            const int rc = fwd2d_stream_f32(in, cA, cH, cV, cD, nr, nc, hlen, f);
+            if (rc <= 0) return rc;
+        }
+    }
     const size_t lds = fwd_fused_lds<T>(hlen);
     if (lds <= kFusedLdsBudget && !force_twopass()) {
         dim3 grid(idiv_up(div2(nc), FTX), idiv_up(div2(nr), FTY));
@@ -508,6 +515,12 @@ template <typename T>
 static int level_inv2d(const T* cA, const T* cH, const T* cV, const T* cD, T* out, T* t1, T* t2, int nri, int nci, int nro, int nco,
                        int hlen, const Taps2<T>& f)
 {
+    if constexpr (sizeof(T) == 4) {
+        if (!force_twopass()) {
+            const int rc = inv2d_stream_f32(cA, cH, cV, cD, out, nri, nci, nro, nco, hlen, f);
+            if (rc <= 0) return rc;
+        }
+    }
     const size_t lds = inv_fused_lds<T>(hlen);
     if (lds <= kFusedLdsBudget && !force_twopass()) {
         dim3 grid(idiv_up(nci, FTX), idiv_up(nri, FTY));
@@ -655,6 +668,10 @@ int pdwt_debug_set(const char* key, int value)
 {
     if (key && !strcmp(key, "force_twopass")) {
         g_force_twopass = value ? 1 : 0;
+        return PDWT_OK;
+    }
+    if (key && !strcmp(key, "stream")) {  // 0: use the LDS-tiled fused kernels instead of the streaming ones
+        stream_set_enabled(value);
         return PDWT_OK;
     }
     return PDWT_EINVAL;

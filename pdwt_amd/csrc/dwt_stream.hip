@@ -1,0 +1,547 @@
+// dwt_stream.hip -- the 2D DWT level kernels of the hot path, float32, "streaming" form for gfx950.
+//
+// One WAVE (64 lanes) owns a vertical strip of the level and walks down it row by row; a workgroup is
+// just 4 independent waves (4 adjacent strips).  No LDS, no __syncthreads.
+//   forward : lane = 4 consecutive input columns (one 16-byte load per row, 1 KiB per wave-row);
+//             the (hlen-2)/2-sample halo on each side comes from the neighbouring lanes through DPP
+//             wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1); the row pass leaves lo/hi for
+//             2 output columns per lane in a register ring of hlen rows; every second input row the
+//             column pass emits one row of A,H,V,D (8-byte stores).
+//   inverse : lane = 2 coefficient columns of each band (8-byte loads); a register ring of hlen/2
+//             coefficient rows feeds the column synthesis (two output rows per new coefficient row);
+//             the row synthesis takes its halo of (t1,t2) from neighbouring lanes by DPP and stores
+//             16 bytes per lane.
+// Strips overlap by the halo lanes (NB per side; 62 valid lanes of 64 for hlen <= 10), so a wave never
+// needs data from another wave and the periodic wrap is just the lane -> column map.
+// Memory pipeline: the row registers of one unrolled body (hlen rows forward, hlen/2 inverse) are
+// re-issued for the rows ONE BODY AHEAD as soon as the row pass has consumed them, so every wave keeps
+// ~hlen KiB of loads in flight while it computes (the per-CU load path, ~10 B/clk, is the resource to
+// keep busy -- MI355X_MICROARCH.md), without a second register buffer.
+// Re-reads: only the hlen-2 halo rows between vertically adjacent chunks (L2 / Infinity Cache hits).
+//
+// Arithmetic (tap order, one FMA per tap, pass order) is identical to the tiled kernels in dwt.hip
+// and to the CPU oracle, so the outputs are bit-identical to both (tests/test_gpu_parity.py).
+// Reference code replaced: w_kern_forward_pass1/2, w_kern_inverse_pass1/2 (src/separable.cu:91-328).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.hpp"
+#include "dwt_stream.hpp"
+
+namespace pdwt {
+
+// bound_ctrl:1 + no `old` operand: the lane without a source reads 0 and the compiler needs no
+// initialising v_mov per shift (that lane is a halo lane and produces no output anyway)
+__device__ __forceinline__ float dpp_shr1(float src)
+{  // lane i <- lane i-1
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_shl1(float src)
+{  // lane i <- lane i+1
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), 0x130, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ int wrapi(int s, int n)
+{
+    s %= n;
+    return s < 0 ? s + n : s;
+}
+// single conditional wrap: valid for -n <= s < 2n (row indices of a chunk; the dispatcher guarantees n >= 2*hlen)
+__device__ __forceinline__ int wrap1(int s, int n) { return s < 0 ? s + n : (s >= n ? s - n : s); }
+
+// compile-time loop: ring slots must be constants for the rings to stay in registers
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for_impl(F&& fn)
+{
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        static_for_impl<I + 1, N>(fn);
+    }
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& fn)
+{
+    static_for_impl<0, N>(fn);
+}
+
+// Packed-f32 arithmetic.  gfx950 issues v_pk_fma_f32 (2 FMAs per lane) in the slot of one VALU op and can
+// broadcast either half of a 64-bit operand (op_sel), so the kernels are written on explicit float pairs:
+//   forward : (lo,hi) += x * (L[k],H[k])   -- one input sample feeds both filters; taps travel as pairs
+//   inverse : (c0,c1) += (band[c0],band[c1]) * tap   -- the two coefficient columns a lane owns
+// Each scalar still accumulates its taps in the reference order with one FMA per tap (bit-exact vs the oracle).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(float x) { return v2f{x, x}; }
+
+// forward taps as (L[k], H[k]) pairs, by value in the kernarg segment (-> SGPR pairs)
+struct TapsLH {
+    v2f t[PDWT_MAX_FILTER_WIDTH];
+};
+
+// =================================================================================================
+// forward
+// =================================================================================================
+template <int HLEN, int NIN_>
+struct FwdGeom {
+    static constexpr int NIN = NIN_;                             // input columns per lane (4: 16-byte loads, 2: 8-byte)
+    static constexpr int C = HLEN / 2 - 1;                       // halo samples on each side of a lane's columns
+    static constexpr int NB = C > 0 ? (C + NIN - 1) / NIN : 0;   // halo lanes per side
+    static constexpr int WIN = NIN * (2 * NB + 1);               // window registers
+    static constexpr int MAXVL = 64 - 2 * NB;                    // lanes that produce output
+};
+
+// Block -> (chunk row, strip group) map.  Workgroups are dispatched round-robin over the 8 XCDs
+// (block b -> XCD b % 8), each with a private L2.  Vertically adjacent chunks share hlen-2 halo rows, so
+// every XCD gets a contiguous band of chunk rows and walks it top to bottom: the halo rows are then L2
+// hits instead of a second trip to Infinity Cache / HBM.  Pure speed: any other placement is still correct.
+struct ChunkMap {
+    int gx;       // workgroups per chunk row
+    int nchunks;  // chunk rows
+    int rpx;      // chunk rows per XCD band = ceil(nchunks / 8)
+};
+__device__ __forceinline__ bool chunk_of_block(const ChunkMap& m, int& cy, int& bx)
+{
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    cy = xcd * m.rpx + slot / m.gx;
+    bx = slot % m.gx;
+    return cy < min(m.nchunks, (xcd + 1) * m.rpx);
+}
+
+template <typename V> struct VecN;
+template <> struct VecN<float4> { static constexpr int N = 4; };
+template <> struct VecN<float2> { static constexpr int N = 2; };
+template <int N> struct VecOf;
+template <> struct VecOf<4> { using type = float4; };
+template <> struct VecOf<2> { using type = float2; };
+template <> struct VecOf<1> { using type = float; };
+__device__ __forceinline__ float vget(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+__device__ __forceinline__ float vget(const float2& v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ void vstore(float* p, const float (&a)[2]) { *reinterpret_cast<float2*>(p) = make_float2(a[0], a[1]); }
+__device__ __forceinline__ void vstore(float* p, const float (&a)[1]) { *p = a[0]; }
+
+template <int HLEN, int NIN>
+__global__ __launch_bounds__(256) void k_fwd2d_stream(const float* __restrict__ in, float* __restrict__ cA, float* __restrict__ cH,
+                                                       float* __restrict__ cV, float* __restrict__ cD, int Nr, int Nc, int R, int VL,
+                                                       ChunkMap cm, TapsLH f)
+{
+    using G = FwdGeom<HLEN, NIN>;
+    using VIN = typename VecOf<NIN>::type;
+    constexpr int NB = G::NB, C = G::C, WIN = G::WIN, P = NIN / 2;
+    int cy, bx;
+    if (!chunk_of_block(cm, cy, bx)) return;
+    const int lane = threadIdx.x & 63;
+    const int strip = bx * 4 + (threadIdx.x >> 6);
+    const int xs = strip * VL * NIN;  // first input column this strip produces outputs for
+    if (xs >= Nc) return;
+    const int Nr2 = Nr >> 1, Nc2 = Nc >> 1;
+    const int y0 = cy * R;
+    const int rows = min(R, Nr2 - y0);
+    if (rows <= 0) return;
+    const int x = xs + NIN * (lane - NB);
+    const bool valid = (lane >= NB) && (lane < NB + VL) && (x < Nc);
+    const int xo = wrapi(x, Nc);  // halo / overhanging lanes hold the periodic continuation
+    const int yb = 2 * y0 - C;
+    const int nin = 2 * rows + HLEN - 2;  // input rows this chunk consumes
+
+    v2f ring[HLEN][P];  // register ring: (lo,hi) row-pass results of the last HLEN input rows
+
+    auto load_row = [&](int r, VIN& v) { v = *reinterpret_cast<const VIN*>(in + (size_t)wrap1(yb + r, Nr) * Nc + xo); };
+
+    auto row_pass = [&](const VIN& v, v2f (&lh)[P]) {
+        float w[WIN];
+#pragma unroll
+        for (int q = 0; q < NIN; q++) w[NB * NIN + q] = vget(v, q);
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int dl = (NB - 1 - k) * NIN, sl = (NB - k) * NIN, dr = (NB + 1 + k) * NIN, sr = (NB + k) * NIN;
+#pragma unroll
+            for (int q = 0; q < NIN; q++) {
+                w[dl + q] = dpp_shr1(w[sl + q]);
+                w[dr + q] = dpp_shl1(w[sr + q]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            v2f acc = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < HLEN; j++) acc = pk_fma(splat(w[NB * NIN - C + 2 * p + j]), f.t[HLEN - 1 - j], acc);
+            lh[p] = acc;
+        }
+    };
+
+    // issue everything the first body needs in one go: ring prologue rows 0..HLEN-3 and body rows
+    VIN v[HLEN];
+    {
+        VIN pv[HLEN > 2 ? HLEN - 2 : 1];
+#pragma unroll
+        for (int r = 0; r < HLEN - 2; r++) load_row(r, pv[r]);
+#pragma unroll
+        for (int u = 0; u < HLEN; u++)
+            if (HLEN - 2 + u < nin) load_row(HLEN - 2 + u, v[u]);
+        static_for<HLEN - 2>([&](auto Rr) {
+            constexpr int r = decltype(Rr)::value;
+            row_pass(pv[r], ring[r]);
+        });
+    }
+
+    const size_t ocol = (size_t)(x >> 1);
+    // one unrolled body = HLEN input rows -> HLEN/2 output rows.  FAST: the body and the one after it
+    // are both complete -> no wave-level branches, so the compiler can count the loads it leaves in flight.
+    auto body = [&](auto FAST, int q0) {
+        constexpr bool fast = decltype(FAST)::value;
+        const int rnext = 2 * q0 + 2 * HLEN - 2;  // chunk-local input row that v[0] holds in the NEXT body
+        static_for<HLEN / 2>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            if (fast || q0 + u < rows) {
+                constexpr int s0 = (2 * u + HLEN - 2) % HLEN, s1 = (2 * u + HLEN - 1) % HLEN;
+                row_pass(v[2 * u], ring[s0]);
+                row_pass(v[2 * u + 1], ring[s1]);
+                // the two row registers are free: re-issue them for the rows one body ahead
+                if (fast || rnext + 2 * u + 1 < nin) {
+                    load_row(rnext + 2 * u, v[2 * u]);
+                    load_row(rnext + 2 * u + 1, v[2 * u + 1]);
+                }
+                v2f ah[P], vd[P];  // (A,H) from the lo branch, (V,D) from the hi branch
+#pragma unroll
+                for (int p = 0; p < P; p++) ah[p] = vd[p] = v2f{0.f, 0.f};
+                static_for<HLEN>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    constexpr int s = (2 * u + j) % HLEN;
+                    const v2f t = f.t[HLEN - 1 - j];
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        ah[p] = pk_fma(splat(ring[s][p].x), t, ah[p]);
+                        vd[p] = pk_fma(splat(ring[s][p].y), t, vd[p]);
+                    }
+                });
+                float a[P], hh[P], vv[P], dd[P];
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    a[p] = ah[p].x;
+                    hh[p] = ah[p].y;
+                    vv[p] = vd[p].x;
+                    dd[p] = vd[p].y;
+                }
+                if (valid) {
+                    const size_t o = (size_t)(y0 + q0 + u) * Nc2 + ocol;
+                    vstore(cA + o, a);
+                    vstore(cH + o, hh);
+                    vstore(cV + o, vv);
+                    vstore(cD + o, dd);
+                }
+            }
+        });
+    };
+    // The first fast body is peeled so that both edges into the loop header carry the same pattern of
+    // outstanding loads/stores: hipcc's s_waitcnt insertion then leaves a full body of loads in flight
+    // (with the un-peeled loop it sized every wait for the prologue edge: at most 2 loads outstanding).
+    int q0 = 0;
+    if (q0 + HLEN <= rows) {
+        body(std::true_type{}, q0);
+        q0 += HLEN / 2;
+        for (; q0 + HLEN <= rows; q0 += HLEN / 2) body(std::true_type{}, q0);
+    }
+    for (; q0 < rows; q0 += HLEN / 2) body(std::false_type{}, q0);
+}
+
+// =================================================================================================
+// inverse
+// =================================================================================================
+template <int HLEN>
+struct InvGeom {
+    static constexpr int H2 = HLEN / 2;
+    static constexpr int C = H2 / 2;
+    static constexpr int SHIFT = (H2 & 1) ? 0 : 1;
+    static constexpr int PC = 2;                                 // coefficient columns per lane
+    static constexpr int NB = C > 0 ? (C + PC - 1) / PC : 0;     // halo lanes per side
+    static constexpr int WIN = PC * (2 * NB + 1);
+    static constexpr int NROWS_EXTRA = H2 - 1 + SHIFT;           // coefficient rows streamed beyond the chunk's own
+    static constexpr int MAXVL = 64 - 2 * NB;
+};
+
+template <int HLEN>
+__global__ __launch_bounds__(256) void k_inv2d_stream(const float* __restrict__ cA, const float* __restrict__ cH,
+                                                       const float* __restrict__ cV, const float* __restrict__ cD, float* __restrict__ out,
+                                                       int Nri, int Nci, int RQ, int VL, ChunkMap cm, Taps2<float> f)
+{
+    using G = InvGeom<HLEN>;
+    constexpr int H2 = G::H2, C = G::C, SHIFT = G::SHIFT, NB = G::NB, WIN = G::WIN;
+    int cy, bx;
+    if (!chunk_of_block(cm, cy, bx)) return;
+    const int lane = threadIdx.x & 63;
+    const int strip = bx * 4 + (threadIdx.x >> 6);
+    const int col0 = strip * VL * 2;
+    if (col0 >= Nci) return;
+    const int cx = col0 + (lane - NB) * 2;
+    const int cxw = wrapi(cx, Nci);
+    const bool valid = (lane >= NB) && (lane < NB + VL) && (cx < Nci);
+    const int Nco = 2 * Nci;
+    const int y0 = cy * RQ;
+    const int rowsq = min(RQ, Nri - y0);
+    if (rowsq <= 0) return;
+    const int yb = y0 - C;
+    const int nrows = rowsq + G::NROWS_EXTRA;
+
+    v2f ra[H2], rhh[H2], rv[H2], rd[H2];  // ring of the last H2 coefficient rows: (col0,col1) of each band
+
+    auto load_row = [&](int r, float2& a, float2& h, float2& v, float2& d) {
+        const size_t o = (size_t)wrap1(yb + r, Nri) * Nci + cxw;
+        a = *reinterpret_cast<const float2*>(cA + o);
+        h = *reinterpret_cast<const float2*>(cH + o);
+        v = *reinterpret_cast<const float2*>(cV + o);
+        d = *reinterpret_cast<const float2*>(cD + o);
+    };
+    auto put = [&](auto S, const float2& a, const float2& h, const float2& v, const float2& d) {
+        constexpr int s = decltype(S)::value;
+        ra[s] = v2f{a.x, a.y};
+        rhh[s] = v2f{h.x, h.y};
+        rv[s] = v2f{v.x, v.y};
+        rd[s] = v2f{d.x, d.y};
+    };
+
+    // one output row: column synthesis from the ring window starting at slot S0 with tap parity OFF,
+    // DPP exchange of (t1,t2), row synthesis, 16-byte store
+    auto emit = [&](auto S0, auto OFF, int gy) {
+        constexpr int s0 = decltype(S0)::value, off = decltype(OFF)::value;
+        v2f sa = {0.f, 0.f}, sh = {0.f, 0.f}, sv = {0.f, 0.f}, sd = {0.f, 0.f};
+        static_for<H2>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int s = (s0 + j) % H2;
+            constexpr int k = HLEN - 1 - (2 * j + off);
+            const v2f fl = splat(f.a[k]), fh = splat(f.b[k]);
+            sa = pk_fma(ra[s], fl, sa);
+            sh = pk_fma(rhh[s], fh, sh);
+            sv = pk_fma(rv[s], fl, sv);
+            sd = pk_fma(rd[s], fh, sd);
+        });
+        const v2f t1o = sa + sh, t2o = sv + sd;
+        float t1[WIN], t2[WIN];
+        t1[NB * 2] = t1o.x;
+        t1[NB * 2 + 1] = t1o.y;
+        t2[NB * 2] = t2o.x;
+        t2[NB * 2 + 1] = t2o.y;
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int dl = (NB - 1 - k) * 2, sl = (NB - k) * 2, dr = (NB + 1 + k) * 2, sr = (NB + k) * 2;
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) {
+                t1[dl + cc] = dpp_shr1(t1[sl + cc]);
+                t2[dl + cc] = dpp_shr1(t2[sl + cc]);
+                t1[dr + cc] = dpp_shl1(t1[sr + cc]);
+                t2[dr + cc] = dpp_shl1(t2[sr + cc]);
+            }
+        }
+        // output e of this lane: window start pl_e - C with pl_e = (e+SHIFT)>>1, tap parity 1-((e+SHIFT)&1).
+        // Outputs that share a window (SHIFT=0: (0,1),(2,3); SHIFT=1: (1,2)) go through one packed chain
+        // with the adjacent-tap pair (F[m-1], F[m]), m = HLEN-1-2j.
+        float o4[4];
+        auto pair_out = [&](auto E0) {
+            constexpr int e0 = decltype(E0)::value;          // parity-1 output; e0+1 is the parity-0 one
+            constexpr int pl = (e0 + SHIFT) >> 1;
+            v2f s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < H2; j++) {
+                const int m = HLEN - 1 - 2 * j;
+                s1 = pk_fma(splat(t1[NB * 2 + pl - C + j]), v2f{f.a[m - 1], f.a[m]}, s1);
+                s2 = pk_fma(splat(t2[NB * 2 + pl - C + j]), v2f{f.b[m - 1], f.b[m]}, s2);
+            }
+            const v2f o = s1 + s2;
+            o4[e0] = o.x;
+            o4[e0 + 1] = o.y;
+        };
+        auto single_out = [&](auto E) {
+            constexpr int eo = decltype(E)::value;
+            constexpr int gp = eo + SHIFT;
+            constexpr int pl = gp >> 1, offx = 1 - (gp & 1);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < H2; j++) {
+                const int k = HLEN - 1 - (2 * j + offx);
+                s1 = __builtin_fmaf(t1[NB * 2 + pl - C + j], f.a[k], s1);
+                s2 = __builtin_fmaf(t2[NB * 2 + pl - C + j], f.b[k], s2);
+            }
+            o4[eo] = s1 + s2;
+        };
+        if constexpr (SHIFT == 0) {
+            pair_out(std::integral_constant<int, 0>{});
+            pair_out(std::integral_constant<int, 2>{});
+        } else {
+            single_out(std::integral_constant<int, 0>{});
+            pair_out(std::integral_constant<int, 1>{});
+            single_out(std::integral_constant<int, 3>{});
+        }
+        if (valid) *reinterpret_cast<float4*>(out + (size_t)gy * Nco + 2 * cx) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    };
+
+    // issue the ring prologue rows 0..H2-2 and the first body's rows together
+    float2 a[H2], h[H2], v[H2], d[H2];
+    {
+        float2 pa[H2 > 1 ? H2 - 1 : 1], ph[H2 > 1 ? H2 - 1 : 1], pv[H2 > 1 ? H2 - 1 : 1], pd[H2 > 1 ? H2 - 1 : 1];
+#pragma unroll
+        for (int r = 0; r < H2 - 1; r++) load_row(r, pa[r], ph[r], pv[r], pd[r]);
+#pragma unroll
+        for (int u = 0; u < H2; u++)
+            if (H2 - 1 + u < nrows) load_row(H2 - 1 + u, a[u], h[u], v[u], d[u]);
+        static_for<H2 - 1>([&](auto Rr) {
+            constexpr int r = decltype(Rr)::value;
+            put(Rr, pa[r], ph[r], pv[r], pd[r]);
+        });
+    }
+
+    // coefficient row H2-1+t completes the ring window of chunk-local rows t .. t+H2-1 (slots (u+j)%H2) and
+    // yields the two output rows that use it:  SHIFT=1: 2t-1 (tap parity 1), 2t (parity 0);  SHIFT=0: 2t, 2t+1
+    const int nsteady = nrows - (H2 - 1);
+    auto body = [&](auto FAST, int t0) {
+        constexpr bool fast = decltype(FAST)::value;
+        static_for<H2>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            const int t = t0 + u;
+            if (fast || t < nsteady) {
+                put(std::integral_constant<int, (H2 - 1 + u) % H2>{}, a[u], h[u], v[u], d[u]);
+                if (fast || H2 - 1 + t + H2 < nrows) load_row(H2 - 1 + t + H2, a[u], h[u], v[u], d[u]);  // one body ahead
+                const int g1 = 2 * t - SHIFT, g0 = g1 + 1;
+                if (fast) {  // interior rows: both outputs exist
+                    emit(std::integral_constant<int, u % H2>{}, std::integral_constant<int, 1>{}, 2 * y0 + g1);
+                    emit(std::integral_constant<int, u % H2>{}, std::integral_constant<int, 0>{}, 2 * y0 + g0);
+                } else {
+                    if (g1 >= 0 && g1 < 2 * rowsq) emit(std::integral_constant<int, u % H2>{}, std::integral_constant<int, 1>{}, 2 * y0 + g1);
+                    if (g0 < 2 * rowsq) emit(std::integral_constant<int, u % H2>{}, std::integral_constant<int, 0>{}, 2 * y0 + g0);
+                }
+            }
+        });
+    };
+    // t = 0 (g1 = -SHIFT may not exist) and the last rows go through the guarded path
+    int t0 = 0;
+    body(std::false_type{}, t0);
+    t0 += H2;
+    if (t0 + 2 * H2 <= nsteady - 1) {  // peeled first fast body: see the forward kernel
+        body(std::true_type{}, t0);
+        t0 += H2;
+        for (; t0 + 2 * H2 <= nsteady - 1; t0 += H2) body(std::true_type{}, t0);
+    }
+    for (; t0 < nsteady; t0 += H2) body(std::false_type{}, t0);
+}
+
+// =================================================================================================
+// host dispatch
+// =================================================================================================
+static int env_int(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+static int g_stream_enable = -1;
+bool stream_enabled()
+{
+    if (g_stream_enable < 0) g_stream_enable = env_int("PDWT_STREAM", 1);
+    return g_stream_enable == 1;
+}
+void stream_set_enabled(int on) { g_stream_enable = on ? 1 : 0; }
+
+// rows of output (forward) / coefficient rows (inverse) per wave: enough waves to fill the chip
+// (256 CUs x 4 SIMDs x a few waves), chunks tall enough to amortise the halo rows
+static int pick_rows(int nrows_total, int strips, int unit)
+{
+    int R = env_int("PDWT_STREAM_R", 0);
+    if (R <= 0) {
+        const long long target_waves = env_int("PDWT_STREAM_WAVES", 8192);
+        R = (int)(((long long)nrows_total * strips) / target_waves);
+        if (R > 64) R = 64;
+        if (R < 2) R = 2;
+    }
+    (void)unit;
+    return R;
+}
+
+static ChunkMap make_map(int gx, int nchunks, dim3* grid)
+{
+    ChunkMap m;
+    m.gx = gx;
+    m.nchunks = nchunks;
+    m.rpx = idiv_up(nchunks, 8);
+    *grid = dim3((unsigned)(8 * m.rpx * gx));
+    return m;
+}
+
+#define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
+
+template <int HLEN, int NIN>
+static int launch_fwd_n(const float* in, float* cA, float* cH, float* cV, float* cD, int nr, int nc, const Taps2<float>& f2)
+{
+    TapsLH f;
+    for (int k = 0; k < PDWT_MAX_FILTER_WIDTH; k++) f.t[k] = v2f{f2.a[k], f2.b[k]};
+    constexpr int MAXVL = FwdGeom<HLEN, NIN>::MAXVL;
+    const int strips = idiv_up(nc, MAXVL * NIN);
+    const int VL = idiv_up(nc / NIN, strips);
+    const int R = pick_rows(nr / 2, strips, HLEN / 2);
+    dim3 grid;
+    const ChunkMap cm = make_map(idiv_up(strips, 4), idiv_up(nr / 2, R), &grid);
+    KTimer kt(K_FWD2D_FUSED);
+    hipLaunchKernelGGL((k_fwd2d_stream<HLEN, NIN>), grid, dim3(256), 0, stream(), in, cA, cH, cV, cD, nr, nc, R, VL, cm, f);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+// wide lanes (16-byte loads) for the big levels, narrow lanes (8-byte loads, twice the waves, half the serial
+// work per wave) once a level is too small to fill the chip with wide ones
+template <int HLEN>
+static int launch_fwd(const float* in, float* cA, float* cH, float* cV, float* cD, int nr, int nc, const Taps2<float>& f)
+{
+    const long long narrow_below = env_int("PDWT_STREAM_NARROW", 2048 * 2048);
+    if ((long long)nr * nc <= narrow_below) return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, nr, nc, f);
+    return launch_fwd_n<HLEN, 4>(in, cA, cH, cV, cD, nr, nc, f);
+}
+
+template <int HLEN>
+static int launch_inv(const float* cA, const float* cH, const float* cV, const float* cD, float* out, int nri, int nci, const Taps2<float>& f)
+{
+    constexpr int MAXVL = InvGeom<HLEN>::MAXVL;
+    const int strips = idiv_up(nci, MAXVL * 2);
+    const int VL = idiv_up(nci / 2, strips);
+    const int RQ = pick_rows(nri, strips, InvGeom<HLEN>::H2);
+    dim3 grid;
+    const ChunkMap cm = make_map(idiv_up(strips, 4), idiv_up(nri, RQ), &grid);
+    KTimer kt(K_INV2D_FUSED);
+    hipLaunchKernelGGL(k_inv2d_stream<HLEN>, grid, dim3(256), 0, stream(), cA, cH, cV, cD, out, nri, nci, RQ, VL, cm, f);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// filter lengths with a streaming instantiation (register budget: one unrolled body holds HLEN rows in flight)
+#define PDWT_STREAM_FWD_HLENS(X) X(4) X(6) X(8) X(10)
+#define PDWT_STREAM_INV_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
+
+int fwd2d_stream_f32(const float* in, float* cA, float* cH, float* cV, float* cD, int nr, int nc, int hlen, const Taps2<float>& f)
+{
+    if (!stream_enabled()) return 1;
+    if ((nr & 1) || (nc & 3) || nc < 64 || nr < 2 * hlen) return 1;
+    if (!al16(in) || !al16(cA) || !al16(cH) || !al16(cV) || !al16(cD)) return 1;
+    switch (hlen) {
+#define X(H) \
+    case H: return launch_fwd<H>(in, cA, cH, cV, cD, nr, nc, f);
+        PDWT_STREAM_FWD_HLENS(X)
+#undef X
+        default: return 1;
+    }
+}
+
+int inv2d_stream_f32(const float* cA, const float* cH, const float* cV, const float* cD, float* out, int nri, int nci, int nro, int nco,
+                     int hlen, const Taps2<float>& f)
+{
+    if (!stream_enabled()) return 1;
+    if ((nci & 1) || nco != 2 * nci || nro != 2 * nri || nci < 32 || nri < 2 * hlen) return 1;
+    if (!al16(out) || !al16(cA) || !al16(cH) || !al16(cV) || !al16(cD)) return 1;
+    switch (hlen) {
+#define X(H) \
+    case H: return launch_inv<H>(cA, cH, cV, cD, out, nri, nci, f);
+        PDWT_STREAM_INV_HLENS(X)
+#undef X
+        default: return 1;
+    }
+}
+
+}  // namespace pdwt

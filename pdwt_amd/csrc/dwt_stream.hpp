@@ -1,0 +1,13 @@
+// dwt_stream.hpp -- entry points of the float32 streaming level kernels (dwt_stream.hip).
+// Return PDWT_OK when the level was launched, 1 when the geometry is outside the fast path
+// (odd sizes, misaligned pointers, unsupported filter length) -> caller uses the tiled kernels.
+#pragma once
+#include "common.hpp"
+
+namespace pdwt {
+int fwd2d_stream_f32(const float* in, float* cA, float* cH, float* cV, float* cD, int nr, int nc, int hlen, const Taps2<float>& f);
+int inv2d_stream_f32(const float* cA, const float* cH, const float* cV, const float* cD, float* out, int nri, int nci, int nro, int nco,
+                     int hlen, const Taps2<float>& f);
+bool stream_enabled();
+void stream_set_enabled(int on);
+}  // namespace pdwt
