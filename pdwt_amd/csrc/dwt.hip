@@ -493,7 +493,9 @@ static int level_fwd2d(const T* in, T* cA, T* cH, T* cV, T* cD, T* t1, T* t2, in
 {
     if constexpr (sizeof(T) == 4) {  // float32 fast path: LDS-free streaming kernel (dwt_stream.hip)
         if (!force_twopass()) {
-            const int rc = fwd2d_stream_f32(in, cA, cH, cV, cD, nr, nc, hlen, f);
+            // t1 (the two-pass scratch) is unused on this path: it serves as the trash area of the streaming kernels
+            float* trash = ((size_t)nr * div2(nc) >= kStreamTrashFloats) ? (float*)t1 : nullptr;
+            const int rc = fwd2d_stream_f32(in, cA, cH, cV, cD, trash, nr, nc, hlen, f);
             if (rc <= 0) return rc;
         }
     }

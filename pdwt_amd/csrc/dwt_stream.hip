@@ -109,22 +109,38 @@ __device__ __forceinline__ bool chunk_of_block(const ChunkMap& m, int& cy, int& 
     return cy < min(m.nchunks, (xcd + 1) * m.rpx);
 }
 
-template <typename V> struct VecN;
-template <> struct VecN<float4> { static constexpr int N = 4; };
-template <> struct VecN<float2> { static constexpr int N = 2; };
+typedef float v4f __attribute__((ext_vector_type(4)));
 template <int N> struct VecOf;
-template <> struct VecOf<4> { using type = float4; };
-template <> struct VecOf<2> { using type = float2; };
-template <> struct VecOf<1> { using type = float; };
-__device__ __forceinline__ float vget(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
-__device__ __forceinline__ float vget(const float2& v, int i) { return i == 0 ? v.x : v.y; }
+template <> struct VecOf<4> { using type = v4f; };
+template <> struct VecOf<2> { using type = v2f; };
 __device__ __forceinline__ void vstore(float* p, const float (&a)[2]) { *reinterpret_cast<float2*>(p) = make_float2(a[0], a[1]); }
 __device__ __forceinline__ void vstore(float* p, const float (&a)[1]) { *p = a[0]; }
+
+// ---- hand-counted memory pipeline (steady-state loop only) -----------------------------------------
+// hipcc sizes every s_waitcnt for the worst incoming edge and, on gfx9, counts stores in vmcnt too, so a
+// compiler-scheduled loop ends every body with vmcnt(0): the wave drains its stores and its prefetched loads
+// before it may compute again.  In the branch-free steady-state bodies all global loads and stores are
+// therefore inline asm (invisible to hipcc's counting) and each consumer waits with an exact
+// `s_waitcnt vmcnt(N)`, N = number of VMEM instructions the wave issues between that load and its use.
+// Memory instructions retire in issue order, so "at most N outstanding" means the load has landed while the
+// N younger loads/stores stay in flight.  Rules that keep the count exact: every lane-predicated store goes
+// to a trash slot instead of being branched around; the loop is entered and left through vmcnt(0).
+__device__ __forceinline__ void asm_load(v4f& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void asm_load(v2f& d, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void asm_store(float* p, v2f d) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(d) : "memory"); }
+__device__ __forceinline__ void asm_store(float* p, float d) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(d) : "memory"); }
+__device__ __forceinline__ void asm_store(float* p, v4f d) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(d) : "memory"); }
+template <int N, typename V>
+__device__ __forceinline__ void asm_wait2(V& a, V& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+template <int N, typename V>
+__device__ __forceinline__ void asm_wait4(V& a, V& b, V& c, V& d) { asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory"); }
+template <typename V>
+__device__ __forceinline__ void asm_drain1(V& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) : : "memory"); }
 
 template <int HLEN, int NIN>
 __global__ __launch_bounds__(256) void k_fwd2d_stream(const float* __restrict__ in, float* __restrict__ cA, float* __restrict__ cH,
                                                        float* __restrict__ cV, float* __restrict__ cD, int Nr, int Nc, int R, int VL,
-                                                       ChunkMap cm, TapsLH f)
+                                                       float* __restrict__ trash, ChunkMap cm, TapsLH f)
 {
     using G = FwdGeom<HLEN, NIN>;
     using VIN = typename VecOf<NIN>::type;
@@ -152,7 +168,7 @@ __global__ __launch_bounds__(256) void k_fwd2d_stream(const float* __restrict__ 
     auto row_pass = [&](const VIN& v, v2f (&lh)[P]) {
         float w[WIN];
 #pragma unroll
-        for (int q = 0; q < NIN; q++) w[NB * NIN + q] = vget(v, q);
+        for (int q = 0; q < NIN; q++) w[NB * NIN + q] = v[q];
 #pragma unroll
         for (int k = 0; k < NB; k++) {
             const int dl = (NB - 1 - k) * NIN, sl = (NB - k) * NIN, dr = (NB + 1 + k) * NIN, sr = (NB + k) * NIN;
@@ -234,14 +250,60 @@ __global__ __launch_bounds__(256) void k_fwd2d_stream(const float* __restrict__ 
             }
         });
     };
-    // The first fast body is peeled so that both edges into the loop header carry the same pattern of
-    // outstanding loads/stores: hipcc's s_waitcnt insertion then leaves a full body of loads in flight
-    // (with the un-peeled loop it sized every wait for the prologue edge: at most 2 loads outstanding).
     int q0 = 0;
     if (q0 + HLEN <= rows) {
-        body(std::true_type{}, q0);
-        q0 += HLEN / 2;
-        for (; q0 + HLEN <= rows; q0 += HLEN / 2) body(std::true_type{}, q0);
+        // ---- steady state: hand-counted pipeline (see asm_load above) ----
+        // per output row: wait(2 rows) . 2 row passes . 2 loads (one body ahead) . column pass . 4 stores
+        // => VMEM instructions between a row's load and its use one body later:
+        constexpr int kAfter = 4 + 6 * (HLEN / 2 - 1);
+        using VOUT = typename std::conditional<P == 2, v2f, float>::type;
+        // invalid (halo / overhanging) lanes store to a private trash slot and never advance
+        float* const tr = trash + (size_t)(blockIdx.x & 255) * 1024 + (threadIdx.x >> 6) * 256 + lane * P;
+        const size_t ostep = valid ? (size_t)Nc2 : 0;
+        float* pA = valid ? cA + (size_t)y0 * Nc2 + ocol : tr;
+        float* pH = valid ? cH + (size_t)y0 * Nc2 + ocol : tr + 64 * P;
+        float* pV = valid ? cV + (size_t)y0 * Nc2 + ocol : tr;
+        float* pD = valid ? cD + (size_t)y0 * Nc2 + ocol : tr + 64 * P;
+        const float* const lbase = in + xo;
+        static_for<HLEN>([&](auto K) { asm_drain1(v[decltype(K)::value]); });
+        for (; q0 + HLEN <= rows; q0 += HLEN / 2) {
+            const int rnext = 2 * q0 + 2 * HLEN - 2;
+            static_for<HLEN / 2>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                constexpr int s0 = (2 * u + HLEN - 2) % HLEN, s1 = (2 * u + HLEN - 1) % HLEN;
+                asm_wait2<kAfter>(v[2 * u], v[2 * u + 1]);
+                row_pass(v[2 * u], ring[s0]);
+                row_pass(v[2 * u + 1], ring[s1]);
+                asm_load(v[2 * u], lbase + (size_t)wrap1(yb + rnext + 2 * u, Nr) * Nc);
+                asm_load(v[2 * u + 1], lbase + (size_t)wrap1(yb + rnext + 2 * u + 1, Nr) * Nc);
+                v2f ah[P], vd[P];
+#pragma unroll
+                for (int p = 0; p < P; p++) ah[p] = vd[p] = v2f{0.f, 0.f};
+                static_for<HLEN>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    constexpr int s = (2 * u + j) % HLEN;
+                    const v2f t = f.t[HLEN - 1 - j];
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        ah[p] = pk_fma(splat(ring[s][p].x), t, ah[p]);
+                        vd[p] = pk_fma(splat(ring[s][p].y), t, vd[p]);
+                    }
+                });
+                const size_t ro = (size_t)(q0 + u) * ostep;
+                if constexpr (P == 2) {
+                    asm_store(pA + ro, VOUT{ah[0].x, ah[1].x});
+                    asm_store(pH + ro, VOUT{ah[0].y, ah[1].y});
+                    asm_store(pV + ro, VOUT{vd[0].x, vd[1].x});
+                    asm_store(pD + ro, VOUT{vd[0].y, vd[1].y});
+                } else {
+                    asm_store(pA + ro, ah[0].x);
+                    asm_store(pH + ro, ah[0].y);
+                    asm_store(pV + ro, vd[0].x);
+                    asm_store(pD + ro, vd[0].y);
+                }
+            });
+        }
+        static_for<HLEN>([&](auto K) { asm_drain1(v[decltype(K)::value]); });
     }
     for (; q0 < rows; q0 += HLEN / 2) body(std::false_type{}, q0);
 }
@@ -469,7 +531,7 @@ static ChunkMap make_map(int gx, int nchunks, dim3* grid)
 #define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
 
 template <int HLEN, int NIN>
-static int launch_fwd_n(const float* in, float* cA, float* cH, float* cV, float* cD, int nr, int nc, const Taps2<float>& f2)
+static int launch_fwd_n(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, int nr, int nc, const Taps2<float>& f2)
 {
     TapsLH f;
     for (int k = 0; k < PDWT_MAX_FILTER_WIDTH; k++) f.t[k] = v2f{f2.a[k], f2.b[k]};
@@ -480,18 +542,18 @@ static int launch_fwd_n(const float* in, float* cA, float* cH, float* cV, float*
     dim3 grid;
     const ChunkMap cm = make_map(idiv_up(strips, 4), idiv_up(nr / 2, R), &grid);
     KTimer kt(K_FWD2D_FUSED);
-    hipLaunchKernelGGL((k_fwd2d_stream<HLEN, NIN>), grid, dim3(256), 0, stream(), in, cA, cH, cV, cD, nr, nc, R, VL, cm, f);
+    hipLaunchKernelGGL((k_fwd2d_stream<HLEN, NIN>), grid, dim3(256), 0, stream(), in, cA, cH, cV, cD, nr, nc, R, VL, trash, cm, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
 // wide lanes (16-byte loads) for the big levels, narrow lanes (8-byte loads, twice the waves, half the serial
 // work per wave) once a level is too small to fill the chip with wide ones
 template <int HLEN>
-static int launch_fwd(const float* in, float* cA, float* cH, float* cV, float* cD, int nr, int nc, const Taps2<float>& f)
+static int launch_fwd(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, int nr, int nc, const Taps2<float>& f)
 {
     const long long narrow_below = env_int("PDWT_STREAM_NARROW", 2048 * 2048);
-    if ((long long)nr * nc <= narrow_below) return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, nr, nc, f);
-    return launch_fwd_n<HLEN, 4>(in, cA, cH, cV, cD, nr, nc, f);
+    if ((long long)nr * nc <= narrow_below) return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, trash, nr, nc, f);
+    return launch_fwd_n<HLEN, 4>(in, cA, cH, cV, cD, trash, nr, nc, f);
 }
 
 template <int HLEN>
@@ -515,14 +577,15 @@ static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 #define PDWT_STREAM_FWD_HLENS(X) X(4) X(6) X(8) X(10)
 #define PDWT_STREAM_INV_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
 
-int fwd2d_stream_f32(const float* in, float* cA, float* cH, float* cV, float* cD, int nr, int nc, int hlen, const Taps2<float>& f)
+int fwd2d_stream_f32(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, int nr, int nc, int hlen,
+                     const Taps2<float>& f)
 {
-    if (!stream_enabled()) return 1;
+    if (!stream_enabled() || !trash) return 1;
     if ((nr & 1) || (nc & 3) || nc < 64 || nr < 2 * hlen) return 1;
     if (!al16(in) || !al16(cA) || !al16(cH) || !al16(cV) || !al16(cD)) return 1;
     switch (hlen) {
 #define X(H) \
-    case H: return launch_fwd<H>(in, cA, cH, cV, cD, nr, nc, f);
+    case H: return launch_fwd<H>(in, cA, cH, cV, cD, trash, nr, nc, f);
         PDWT_STREAM_FWD_HLENS(X)
 #undef X
         default: return 1;
