@@ -1,0 +1,69 @@
+"""Batch split of the hot path over the GPUs of one node (BASELINE.json north_star).
+
+The reference is single-GPU.  Rows of a batched-1D array are independent signals
+(reference src/separable.cu:213) and whole 2D images are independent, so the batch shards with NO
+data-path collective: every rank owns a contiguous block of rows (or whole images) and a private
+``Wavelets`` instance on its own GPU.  The only exchange steps are
+  * ``norm1()``: one all-reduce(SUM) of a single float64 per call (RCCL over xGMI on GPUs);
+  * optional gather of results to rank 0 for inspection (outside any timed region).
+One process per GPU: ``torch.distributed`` with backend "nccl" (= RCCL) in production, "gloo" in the
+CPU tests (tests/test_batch_shard.py), where the per-shard engine is injected.
+"""
+import numpy as np
+
+
+def shard_rows(n_rows, world, rank):
+    """Contiguous row block [start, start+count) of rank `rank`; the first n_rows % world ranks get one more."""
+    base, rem = divmod(int(n_rows), int(world))
+    start = rank * base + min(rank, rem)
+    return start, base + (1 if rank < rem else 0)
+
+
+class ShardedBatch:
+    """A batch of independent 1D signals (rows) or 2D images, split across the ranks of a process group.
+
+    engine_factory(local_array) -> object with forward(), inverse(), soft_threshold(beta, app, norm),
+    norm1_f64(), get_image(), coeffs.  Default: pdwt_amd.Wavelets on this rank's GPU.
+    """
+
+    def __init__(self, local_rows, wname, levels, ndim=1, do_swt=0, group=None, engine_factory=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if engine_factory is None:
+            import pdwt_amd
+
+            def engine_factory(a):
+                return pdwt_amd.Wavelets(a, wname, levels, do_swt=do_swt, ndim=ndim)
+        self.W = engine_factory(np.ascontiguousarray(local_rows))
+
+    def forward(self):
+        self.W.forward()
+
+    def inverse(self):
+        self.W.inverse()
+
+    def soft_threshold(self, beta, do_thresh_appcoeffs=0, normalize=0):
+        self.W.soft_threshold(beta, do_thresh_appcoeffs, normalize)  # elementwise: shard-local
+
+    def norm1(self):
+        """L1 norm of ALL coefficients of the whole batch: per-shard double partial + all-reduce(SUM)."""
+        import torch
+        local = float(self.W.norm1_f64())
+        if self.world == 1:
+            return local
+        dev = "cuda" if self.dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor([local], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return float(t.item())
+
+    def gather_image(self, dst=0):
+        """All shards' reconstructed rows stacked in rank order on rank `dst` (None elsewhere)."""
+        local = self.W.get_image()
+        if self.world == 1:
+            return local
+        out = [None] * self.world if self.rank == dst else None
+        self.dist.gather_object(local, out, dst=dst, group=self.group)
+        return np.concatenate(out, axis=0) if self.rank == dst else None

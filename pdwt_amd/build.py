@@ -68,8 +68,21 @@ def build_host(force=False):
     return outs
 
 
+def build_demo(force=False):
+    """The drop-in acceptance program (examples/demo.cpp) against include/wt.h + libpdwt.so / libpdwtd.so."""
+    src = os.path.join(ROOT, "examples", "demo.cpp")
+    outs = []
+    for name, lib, flags in (("demo", "pdwt", []), ("demod", "pdwtd", ["-DDOUBLEPRECISION"])):
+        out = os.path.join(LIB, name)
+        if force or _newer([src, os.path.join(INC, "wt.h"), os.path.join(LIB, "lib%s.so" % lib)], out):
+            _run(["g++", "-O2", "-std=c++17", "-Wall"] + flags + ["-I" + INC, src, "-L" + LIB, "-l" + lib, "-lpdwt_hip",
+                  "-Wl,-rpath,$ORIGIN", "-o", out])
+        outs.append(out)
+    return outs
+
+
 def build_all(force=False):
-    return [build_hip(force)] + build_host(force)
+    return [build_hip(force)] + build_host(force) + build_demo(force)
 
 
 if __name__ == "__main__":

@@ -313,3 +313,30 @@ def test_config5_f64_db20_L6_threshold_norm1_reduced():
     W.inverse()
     O.inverse()
     assert band_err(W.get_image(), O.get_image()) <= 1e-10
+
+
+def test_dropin_demo_program(tmp_path):
+    """examples/demo.cpp (plain host C++ against include/wt.h, the reference's demo.cpp call sequence)
+    on the reference's own lena.dat: approximation band and thresholded reconstruction vs the oracle."""
+    import subprocess
+    from tests.helpers import ROOT
+    lena = np.fromfile(GOLDEN + "/lena.dat", dtype=np.float32).reshape(512, 512)
+    for exe, dt in (("demo", np.float32), ("demod", np.float64)):
+        out = str(tmp_path / (exe + ".bin"))
+        r = subprocess.run([ROOT + "/pdwt_amd/lib/" + exe, GOLDEN + "/lena.dat", "512", "512", "db4", "3", out], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "demo OK" in r.stdout, r.stdout + r.stderr
+        raw = open(out, "rb").read()
+        nels = int(np.frombuffer(raw[:4], dtype=np.int32)[0])
+        assert nels == 64 * 64
+        band = np.frombuffer(raw[4:4 + nels * dt().itemsize], dtype=dt).reshape(64, 64)
+        rec = np.frombuffer(raw[4 + nels * dt().itemsize:], dtype=dt).reshape(512, 512)
+        O = orc.OracleWavelets(lena.astype(dt), "db4", 3)
+        O.forward()
+        assert band_err(band, O.get_coeff(0)) <= TOL[np.dtype(dt)]
+        n_before = O.norm1_f64()
+        O.soft_threshold(90.0)
+        n_after = O.norm1_f64()
+        O.inverse()
+        assert band_err(rec, O.get_image()) <= TOL[np.dtype(dt)]
+        vals = [float(l.split("=")[1]) for l in r.stdout.splitlines() if "L1 =" in l]
+        assert abs(vals[0] - n_before) <= 2e-6 * n_before and abs(vals[1] - n_after) <= 2e-6 * n_after
