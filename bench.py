@@ -77,7 +77,8 @@ def algorithmic_bytes(cfg, levels_eff):
                           "ana_rows": 2 * n * sz, "ana_cols": 2 * n * sz, "syn_cols": 2 * n * sz, "syn_rows": 2 * n * sz,
                           "haar2d_fwd": 2 * n * sz, "haar2d_inv": 2 * n * sz}
         else:
-            per_kernel = {"ana_rows": 2 * n * sz, "syn_rows": 2 * n * sz, "haar1d_fwd": 2 * n * sz, "haar1d_inv": 2 * n * sz}
+            # batched 1D runs ALL levels in one launch (dwt1d_fused.hip): read the batch once, write every band once
+            per_kernel = {"ana_rows": 2 * N * sz, "syn_rows": 2 * N * sz, "haar1d_fwd": 2 * n * sz, "haar1d_inv": 2 * n * sz}
     return step, per_kernel
 
 

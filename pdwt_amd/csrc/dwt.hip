@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "common.hpp"
+#include "dwt1d_fused.hpp"
 #include "dwt_stream.hpp"
 
 namespace pdwt {
@@ -627,6 +628,10 @@ static int forward_separable_1d(T* d_image, T** c, T* d_tmp, pdwt_info w, const 
     int rc = check_args(d_image, c, d_tmp, w, 1, true, filt, filt ? filt->hlen : 0);
     if (rc != PDWT_OK) return rc;
     const Taps2<T> f = taps_fwd<T>(filt);
+    if (!force_twopass()) {  // all levels in one launch, row resident in LDS (dwt1d_fused.hip)
+        rc = fwd1d_fused<T>(d_image, c, w, f);
+        if (rc <= 0) return rc;
+    }
     Scratch<T> s(d_tmp, w.Nr, w.Nc, 1);
     const T* in = d_image;
     int nc = w.Nc;
@@ -647,6 +652,10 @@ static int inverse_separable_1d(T* d_image, T** c, T* d_tmp, pdwt_info w, const 
     int rc = check_args(d_image, c, d_tmp, w, 1, true, filt, filt ? filt->hlen : 0);
     if (rc != PDWT_OK) return rc;
     const Taps2<T> f = taps_inv<T>(filt);
+    if (!force_twopass()) {
+        rc = inv1d_fused<T>(d_image, c, w, f);
+        if (rc <= 0) return rc;
+    }
     Scratch<T> s(d_tmp, w.Nr, w.Nc, 1);
     int tNc[34];
     tNc[0] = w.Nc;
