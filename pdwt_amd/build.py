@@ -45,13 +45,26 @@ def hipcc():
 
 
 def build_hip(force=False):
+    """Compile every HIP translation unit to an object (in parallel), then link libpdwt_hip.so."""
+    from concurrent.futures import ThreadPoolExecutor
     out = os.path.join(LIB, "libpdwt_hip.so")
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, d) for d in HIP_DEPS] + [os.path.join(INC, "pdwt_hip.h")]
-    if force or _newer(deps, out):
-        os.makedirs(LIB, exist_ok=True)
-        extra = os.environ.get("PDWT_HIPCC_FLAGS", "").split()
-        _run([hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall"] + extra + ["-o", out] + srcs)
+    objdir = os.path.join(PKG, "build")
+    hdrs = [os.path.join(CSRC, d) for d in HIP_DEPS] + [os.path.join(INC, "pdwt_hip.h")]
+    extra = os.environ.get("PDWT_HIPCC_FLAGS", "").split()
+    os.makedirs(LIB, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
+    jobs, objs = [], []
+    for src in HIP_SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or extra or _newer([sp] + hdrs, obj):
+            jobs.append([hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall"] + extra + ["-c", sp, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    if jobs or not os.path.exists(out):
+        _run([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs)
     return out
 
 

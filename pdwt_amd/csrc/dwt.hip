@@ -173,23 +173,32 @@ __global__ __launch_bounds__(kThreads) void k_inv2d_fused(const T* __restrict__ 
     }
     __syncthreads();
 
-    // row synthesis + store: out = t1*IL + t2*IH
+    // row synthesis + store: out = t1*IL + t2*IH.  One lane = one PAIR of adjacent outputs (2u, 2u+1): the tap
+    // parity of each output is then a compile-time/uniform quantity and the taps stay scalar operands (a
+    // per-lane parity turns f.a[k] into a divergent private-memory lookup -- the reference's kernel has the
+    // same divergence on its constant cache, src/separable.cu:310-326).
     for (int gyl = ty; gyl < 2 * TY; gyl += 4) {
         const int gy = 2 * y0 + gyl;
         if (gy >= Nro) break;
-        for (int gxl = tx; gxl < 2 * TX; gxl += 64) {
-            const int gp = gxl + shift;
-            const int pl = gp >> 1, off = 1 - (gp & 1);
-            T s1 = 0, s2 = 0;
-            const int base = gyl * CCP + pl;
+        for (int u = tx; u < TX; u += 64) {
+            T res[2];
 #pragma unroll
-            for (int j = 0; j < h2; j++) {
-                const int k = hlen - 1 - (2 * j + off);
-                s1 = fma_t(s_t1[base + j], f.a[k], s1);
-                s2 = fma_t(s_t2[base + j], f.b[k], s2);
+            for (int e = 0; e < 2; e++) {
+                const int gp = 2 * u + e + shift;
+                const int pl = gp >> 1, off = 1 - ((e + shift) & 1);
+                T s1 = 0, s2 = 0;
+                const int base = gyl * CCP + pl;
+#pragma unroll
+                for (int j = 0; j < h2; j++) {
+                    const int k = hlen - 1 - (2 * j + off);
+                    s1 = fma_t(s_t1[base + j], f.a[k], s1);
+                    s2 = fma_t(s_t2[base + j], f.b[k], s2);
+                }
+                res[e] = s1 + s2;
             }
-            const int gx = 2 * x0 + gxl;
-            if (gx < Nco) out[(size_t)gy * Nco + gx] = s1 + s2;
+            const int gx = 2 * x0 + 2 * u;
+            if (gx < Nco) out[(size_t)gy * Nco + gx] = res[0];
+            if (gx + 1 < Nco) out[(size_t)gy * Nco + gx + 1] = res[1];
         }
     }
 }
@@ -379,19 +388,26 @@ __global__ __launch_bounds__(kThreads) void k_syn_rows(const T* __restrict__ a, 
     }
     __syncthreads();
     if (row >= Nr) return;
-    for (int gxl = lane; gxl < 2 * TXC; gxl += 64) {
-        const int gx = 2 * x0 + gxl;
+    // one lane = one pair of adjacent outputs: uniform tap parity per accumulator (see k_inv2d_fused)
+    for (int u = lane; u < TXC; u += 64) {
+        const int gx = 2 * x0 + 2 * u;
         if (gx >= Nco) break;
-        const int gp = gxl + shift;
-        const int pl = gp >> 1, off = 1 - (gp & 1);
-        T s1 = 0, s2 = 0;
+        T res[2];
 #pragma unroll
-        for (int j = 0; j < h2; j++) {
-            const int k = hlen - 1 - (2 * j + off);
-            s1 = fma_t(sa[pl + j], f.a[k], s1);
-            s2 = fma_t(sd[pl + j], f.b[k], s2);
+        for (int e = 0; e < 2; e++) {
+            const int gp = 2 * u + e + shift;
+            const int pl = gp >> 1, off = 1 - ((e + shift) & 1);
+            T s1 = 0, s2 = 0;
+#pragma unroll
+            for (int j = 0; j < h2; j++) {
+                const int k = hlen - 1 - (2 * j + off);
+                s1 = fma_t(sa[pl + j], f.a[k], s1);
+                s2 = fma_t(sd[pl + j], f.b[k], s2);
+            }
+            res[e] = s1 + s2;
         }
-        out[(size_t)row * Nco + gx] = s1 + s2;
+        out[(size_t)row * Nco + gx] = res[0];
+        if (gx + 1 < Nco) out[(size_t)row * Nco + gx + 1] = res[1];
     }
 }
 
@@ -434,6 +450,10 @@ static size_t inv_fused_lds(int hlen)
 
 #define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
 
+// Filter lengths with a compile-time instantiation of the tiled kernels (tap loops fully unrolled, taps
+// in SGPRs instead of one scalar load + wait per tap); any other length runs the HLEN=0 (runtime) form.
+#define PDWT_TILED_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(24) X(30) X(40)
+
 // ---- level launchers --------------------------------------------------------------------------
 template <typename T>
 static int launch_ana_rows(const T* in, T* lo, T* hi, int Nr, int Nc, int hlen, const Taps2<T>& f)
@@ -441,8 +461,15 @@ static int launch_ana_rows(const T* in, T* lo, T* hi, int Nr, int Nc, int hlen, 
     constexpr int TXO = 256;
     const size_t lds = 4 * (size_t)((2 * TXO + hlen - 2) | 1) * sizeof(T);
     dim3 grid(idiv_up(div2(Nc), TXO), idiv_up(Nr, 4));
+    void (*k)(const T*, T*, T*, int, int, int, Taps2<T>);
+    switch (hlen) {
+#define X(H) case H: k = k_ana_rows<T, H, TXO>; break;
+        PDWT_TILED_HLENS(X)
+#undef X
+        default: k = k_ana_rows<T, 0, TXO>; break;
+    }
     KTimer kt(K_ANA_ROWS);
-    hipLaunchKernelGGL((k_ana_rows<T, 0, TXO>), grid, dim3(kThreads), lds, stream(), in, lo, hi, Nr, Nc, hlen, f);
+    hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream(), in, lo, hi, Nr, Nc, hlen, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -453,8 +480,15 @@ static int launch_syn_rows(const T* a, const T* d, T* out, int Nr, int Nci, int 
     constexpr int TXC = 128;
     const size_t lds = 4 * 2 * (size_t)(TXC + hlen / 2) * sizeof(T);
     dim3 grid(idiv_up(Nci, TXC), idiv_up(Nr, 4));
+    void (*k)(const T*, const T*, T*, int, int, int, int, Taps2<T>);
+    switch (hlen) {
+#define X(H) case H: k = k_syn_rows<T, H, TXC>; break;
+        PDWT_TILED_HLENS(X)
+#undef X
+        default: k = k_syn_rows<T, 0, TXC>; break;
+    }
     KTimer kt(K_SYN_ROWS);
-    hipLaunchKernelGGL((k_syn_rows<T, 0, TXC>), grid, dim3(kThreads), lds, stream(), a, d, out, Nr, Nci, Nco, hlen, f);
+    hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream(), a, d, out, Nr, Nci, Nco, hlen, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -464,7 +498,13 @@ static int launch_ana_cols(const T* t1, const T* t2, T* cA, T* cH, T* cV, T* cD,
 {
     constexpr int TYO = 16;
     const size_t lds = 2 * (size_t)(2 * TYO + hlen - 2) * 64 * sizeof(T);
-    auto k = k_ana_cols<T, 0, TYO>;
+    void (*k)(const T*, const T*, T*, T*, T*, T*, int, int, int, Taps2<T>);
+    switch (hlen) {
+#define X(H) case H: k = k_ana_cols<T, H, TYO>; break;
+        PDWT_TILED_HLENS(X)
+#undef X
+        default: k = k_ana_cols<T, 0, TYO>; break;
+    }
     if (set_lds(k, lds) != PDWT_OK) return PDWT_EHIP;
     dim3 grid(idiv_up(Ncw, 64), idiv_up(div2(Nr), TYO));
     KTimer kt(K_ANA_COLS);
@@ -479,7 +519,13 @@ static int launch_syn_cols(const T* cA, const T* cH, const T* cV, const T* cD, T
 {
     constexpr int TYC = 16;
     const size_t lds = 4 * (size_t)(TYC + hlen / 2) * 64 * sizeof(T);
-    auto k = k_syn_cols<T, 0, TYC>;
+    void (*k)(const T*, const T*, const T*, const T*, T*, T*, int, int, int, int, Taps2<T>);
+    switch (hlen) {
+#define X(H) case H: k = k_syn_cols<T, H, TYC>; break;
+        PDWT_TILED_HLENS(X)
+#undef X
+        default: k = k_syn_cols<T, 0, TYC>; break;
+    }
     if (set_lds(k, lds) != PDWT_OK) return PDWT_EHIP;
     dim3 grid(idiv_up(Nc, 64), idiv_up(Nri, TYC));
     KTimer kt(K_SYN_COLS);
@@ -503,8 +549,15 @@ static int level_fwd2d(const T* in, T* cA, T* cH, T* cV, T* cD, T* t1, T* t2, in
     const size_t lds = fwd_fused_lds<T>(hlen);
     if (lds <= kFusedLdsBudget && !force_twopass()) {
         dim3 grid(idiv_up(div2(nc), FTX), idiv_up(div2(nr), FTY));
+        void (*k)(const T*, T*, T*, T*, T*, int, int, int, Taps2<T>);
+        switch (hlen) {
+#define X(H) case H: k = k_fwd2d_fused<T, H, FTX, FTY>; break;
+            PDWT_TILED_HLENS(X)
+#undef X
+            default: k = k_fwd2d_fused<T, 0, FTX, FTY>; break;
+        }
         KTimer kt(K_FWD2D_FUSED);
-        hipLaunchKernelGGL((k_fwd2d_fused<T, 0, FTX, FTY>), grid, dim3(kThreads), lds, stream(), in, cA, cH, cV, cD, nr, nc, hlen, f);
+        hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream(), in, cA, cH, cV, cD, nr, nc, hlen, f);
         PDWT_CHECK_LAUNCH();
         return PDWT_OK;
     }
@@ -527,9 +580,15 @@ static int level_inv2d(const T* cA, const T* cH, const T* cV, const T* cD, T* ou
     const size_t lds = inv_fused_lds<T>(hlen);
     if (lds <= kFusedLdsBudget && !force_twopass()) {
         dim3 grid(idiv_up(nci, FTX), idiv_up(nri, FTY));
+        void (*k)(const T*, const T*, const T*, const T*, T*, int, int, int, int, int, Taps2<T>);
+        switch (hlen) {
+#define X(H) case H: k = k_inv2d_fused<T, H, FTX, FTY>; break;
+            PDWT_TILED_HLENS(X)
+#undef X
+            default: k = k_inv2d_fused<T, 0, FTX, FTY>; break;
+        }
         KTimer kt(K_INV2D_FUSED);
-        hipLaunchKernelGGL((k_inv2d_fused<T, 0, FTX, FTY>), grid, dim3(kThreads), lds, stream(), cA, cH, cV, cD, out, nri, nci, nro, nco,
-                           hlen, f);
+        hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream(), cA, cH, cV, cD, out, nri, nci, nro, nco, hlen, f);
         PDWT_CHECK_LAUNCH();
         return PDWT_OK;
     }
