@@ -1,0 +1,9 @@
+// cols_ring.hpp -- register-ring column passes (cols_ring.hip).  Return PDWT_OK when launched, 1 when the
+// filter length has no instantiation (caller falls back to the LDS-tiled kernels), negative on error.
+#pragma once
+#include "common.hpp"
+
+namespace pdwt {
+template <typename T> int ana_cols_ring(const T* t, T* lo, T* hi, int Nr, int Ncw, int hlen, const Taps2<T>& f);
+template <typename T> int syn_cols_ring(const T* ca, const T* cd, T* out, int Nri, int Nc, int Nro, int hlen, const Taps2<T>& f);
+}  // namespace pdwt

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "common.hpp"
+#include "cols_ring.hpp"
 #include "dwt1d_fused.hpp"
 #include "dwt_stream.hpp"
 
@@ -432,6 +433,17 @@ static bool force_twopass()
     return g_force_twopass == 1;
 }
 
+// test / tuning knob: use the LDS-tiled column kernels even where a register-ring instantiation exists
+static int g_tiled_cols = -1;
+static bool tiled_cols_forced()
+{
+    if (g_tiled_cols < 0) {
+        const char* e = getenv("PDWT_TILED_COLS");
+        g_tiled_cols = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_tiled_cols == 1;
+}
+
 constexpr int FTX = 64, FTY = 16;           // fused tile (outputs per band / coefficient tile)
 constexpr size_t kFusedLdsBudget = 64 * 1024;  // keep >= 2 workgroups per CU (160 KiB LDS)
 
@@ -496,6 +508,12 @@ static int launch_syn_rows(const T* a, const T* d, T* out, int Nr, int Nci, int 
 template <typename T>
 static int launch_ana_cols(const T* t1, const T* t2, T* cA, T* cH, T* cV, T* cD, int Nr, int Ncw, int hlen, const Taps2<T>& f)
 {
+    if (!tiled_cols_forced()) {  // register-ring kernels (cols_ring.hip): one launch per branch
+        KTimer kt(K_ANA_COLS);
+        int rc = ana_cols_ring<T>(t1, cA, cH, Nr, Ncw, hlen, f);
+        if (rc == PDWT_OK) rc = ana_cols_ring<T>(t2, cV, cD, Nr, Ncw, hlen, f);
+        if (rc <= 0) return rc;
+    }
     constexpr int TYO = 16;
     const size_t lds = 2 * (size_t)(2 * TYO + hlen - 2) * 64 * sizeof(T);
     void (*k)(const T*, const T*, T*, T*, T*, T*, int, int, int, Taps2<T>);
@@ -517,6 +535,12 @@ template <typename T>
 static int launch_syn_cols(const T* cA, const T* cH, const T* cV, const T* cD, T* t1, T* t2, int Nri, int Nc, int Nro, int hlen,
                            const Taps2<T>& f)
 {
+    if (!tiled_cols_forced()) {
+        KTimer kt(K_SYN_COLS);
+        int rc = syn_cols_ring<T>(cA, cH, t1, Nri, Nc, Nro, hlen, f);
+        if (rc == PDWT_OK) rc = syn_cols_ring<T>(cV, cD, t2, Nri, Nc, Nro, hlen, f);
+        if (rc <= 0) return rc;
+    }
     constexpr int TYC = 16;
     const size_t lds = 4 * (size_t)(TYC + hlen / 2) * 64 * sizeof(T);
     void (*k)(const T*, const T*, const T*, const T*, T*, T*, int, int, int, int, Taps2<T>);
@@ -738,6 +762,10 @@ int pdwt_debug_set(const char* key, int value)
 {
     if (key && !strcmp(key, "force_twopass")) {
         g_force_twopass = value ? 1 : 0;
+        return PDWT_OK;
+    }
+    if (key && !strcmp(key, "tiled_cols")) {  // 1: LDS-tiled column kernels instead of the register-ring ones
+        g_tiled_cols = value ? 1 : 0;
         return PDWT_OK;
     }
     if (key && !strcmp(key, "stream")) {  // 0: use the LDS-tiled fused kernels instead of the streaming ones

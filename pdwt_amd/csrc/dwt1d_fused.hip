@@ -463,7 +463,8 @@ static int launch_fwd(const T* in, T** c, const pdwt_info& w, const Taps2<T>& f)
     Bands1D<T> b;
     if (!fill_bands(b, c, w)) return 1;
     using G = Fwd1DGeom<T, HLEN>;
-    const size_t lds = ((size_t)G::buf_elems(w.Nc) + (size_t)G::buf_elems(b.n[1])) * sizeof(T);
+    // a single level never writes the second buffer (its approximation goes straight to HBM)
+    const size_t lds = ((size_t)G::buf_elems(w.Nc) + (w.nlevels > 1 ? (size_t)G::buf_elems(b.n[1]) : 0)) * sizeof(T);
     if (lds > kLdsBudget1D) return 1;
     constexpr int NVh = Vec16<T>::N;
     const bool pre = (w.Nc % NVh) == 0 && ((uintptr_t)in & 15) == 0 && (w.Nc / NVh) <= kPre1D * 256;
@@ -484,7 +485,8 @@ static int launch_inv(T* out, T** c, const pdwt_info& w, const Taps2<T>& f)
     Bands1D<T> b;
     if (!fill_bands(b, c, w)) return 1;
     using G = Inv1DGeom<T, HLEN>;
-    const size_t lds = 3 * (size_t)G::buf_elems(b.n[1]) * sizeof(T);
+    // a single level writes the image row straight to HBM: no output buffer in LDS
+    const size_t lds = (w.nlevels > 1 ? 3 : 2) * (size_t)G::buf_elems(b.n[1]) * sizeof(T);
     if (lds > kLdsBudget1D) return 1;
     constexpr int NVh = Vec16<T>::N;
     bool pf = w.nlevels <= kInvMaxLev && (w.Nc % NVh) == 0 && ((uintptr_t)out & 15) == 0;
