@@ -187,6 +187,136 @@ __global__ __launch_bounds__(256) void k_syn_cols_ring(const T* __restrict__ ca,
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Stationary (a-trous) column passes, level with tap spacing f = 2^(level-1).  Rows r = rho (mod f) form
+// f independent sub-signals of M = Nr/f samples on which the dilated filter is an ordinary dense filter
+// (the periodic wrap stays inside a residue class because f divides Nr): one wave = one column strip x one
+// residue class x a chunk of the sub-signal, with the same register ring as above -- every row is read
+// once per chunk instead of hlen times (reference: src/separable.cu:452-493, 553-589; math A-3 / A-4).
+// -------------------------------------------------------------------------------------------------
+template <typename T, int HLEN, int CPL>
+__global__ __launch_bounds__(256) void k_swt_ana_cols_ring(const T* __restrict__ t, T* __restrict__ lo, T* __restrict__ hi, int Nr, int Nc,
+                                                            int fct, int RO, Taps2<T> f)
+{
+    using V = typename VecT<T, CPL>::type;
+    constexpr int C = HLEN / 2 - 1;
+    constexpr int RS = HLEN + kRingPF;
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int x0 = (strip * 64 + lane) * CPL;
+    if (strip * 64 * CPL >= Nc) return;
+    const bool active = x0 < Nc;
+    const int xl = active ? x0 : 0;
+    const int M = Nr / fct;
+    const int rho = blockIdx.y % fct;
+    const int m0 = (blockIdx.y / fct) * RO;
+    const int nout = min(RO, M - m0);
+    if (nout <= 0) return;
+    const int nin = nout + HLEN - 1;
+
+    V ring[RS];
+    auto row_ptr = [&](int r) {
+        const int sub = wrap_per(m0 - C + min(r, nin - 1), M);
+        return reinterpret_cast<const V*>(t + (size_t)(rho + fct * sub) * Nc + xl);
+    };
+    cfor<RS>([&](auto S) { ring[decltype(S)::value] = *row_ptr(decltype(S)::value); });
+
+    for (int q0 = 0; q0 < nout; q0 += RS) {
+        cfor<RS>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            const int q = q0 + u;
+            if (q < nout) {
+                T al[CPL], ah[CPL];
+#pragma unroll
+                for (int p = 0; p < CPL; p++) al[p] = ah[p] = T(0);
+                cfor<HLEN>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    constexpr int s = (u + j) % RS;
+                    const T fl = f.a[HLEN - 1 - j], fh = f.b[HLEN - 1 - j];
+#pragma unroll
+                    for (int p = 0; p < CPL; p++) {
+                        const T v = vget<T, CPL>(ring[s], p);
+                        al[p] = fma_t(v, fl, al[p]);
+                        ah[p] = fma_t(v, fh, ah[p]);
+                    }
+                });
+                if (active) {
+                    V vl, vh;
+#pragma unroll
+                    for (int p = 0; p < CPL; p++) {
+                        vset<T, CPL>(vl, p, al[p]);
+                        vset<T, CPL>(vh, p, ah[p]);
+                    }
+                    const size_t o = (size_t)(rho + fct * (m0 + q)) * Nc + x0;
+                    *reinterpret_cast<V*>(lo + o) = vl;
+                    *reinterpret_cast<V*>(hi + o) = vh;
+                }
+            }
+            ring[u] = *row_ptr(q + RS);  // row q of the chunk is dead
+        });
+    }
+}
+
+// out = a * (IL/2) + d * (IH/2) along columns (taps pre-halved by the caller), centre c = (hlen/2) * f
+template <typename T, int HLEN, int CPL>
+__global__ __launch_bounds__(256) void k_swt_syn_cols_ring(const T* __restrict__ ca, const T* __restrict__ cd, T* __restrict__ out, int Nr,
+                                                            int Nc, int fct, int RO, Taps2<T> f)
+{
+    using V = typename VecT<T, CPL>::type;
+    constexpr int C = HLEN / 2;
+    constexpr int RS = HLEN + kRingPF;
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int x0 = (strip * 64 + lane) * CPL;
+    if (strip * 64 * CPL >= Nc) return;
+    const bool active = x0 < Nc;
+    const int xl = active ? x0 : 0;
+    const int M = Nr / fct;
+    const int rho = blockIdx.y % fct;
+    const int m0 = (blockIdx.y / fct) * RO;
+    const int nout = min(RO, M - m0);
+    if (nout <= 0) return;
+    const int nin = nout + HLEN - 1;
+
+    V ra[RS], rd[RS];
+    auto off_of = [&](int r) { return (size_t)(rho + fct * wrap_per(m0 - C + min(r, nin - 1), M)) * Nc + xl; };
+    cfor<RS>([&](auto S) {
+        const size_t o = off_of(decltype(S)::value);
+        ra[decltype(S)::value] = *reinterpret_cast<const V*>(ca + o);
+        rd[decltype(S)::value] = *reinterpret_cast<const V*>(cd + o);
+    });
+    for (int q0 = 0; q0 < nout; q0 += RS) {
+        cfor<RS>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            const int q = q0 + u;
+            if (q < nout) {
+                T sa[CPL], sd[CPL];
+#pragma unroll
+                for (int p = 0; p < CPL; p++) sa[p] = sd[p] = T(0);
+                cfor<HLEN>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    constexpr int s = (u + j) % RS;
+                    const T fl = f.a[HLEN - 1 - j], fh = f.b[HLEN - 1 - j];
+#pragma unroll
+                    for (int p = 0; p < CPL; p++) {
+                        sa[p] = fma_t(vget<T, CPL>(ra[s], p), fl, sa[p]);
+                        sd[p] = fma_t(vget<T, CPL>(rd[s], p), fh, sd[p]);
+                    }
+                });
+                if (active) {
+                    V r;
+#pragma unroll
+                    for (int p = 0; p < CPL; p++) vset<T, CPL>(r, p, sa[p] + sd[p]);
+                    *reinterpret_cast<V*>(out + (size_t)(rho + fct * (m0 + q)) * Nc + x0) = r;
+                }
+            }
+            const size_t o = off_of(q + RS);
+            ra[u] = *reinterpret_cast<const V*>(ca + o);
+            rd[u] = *reinterpret_cast<const V*>(cd + o);
+        });
+    }
+}
+
 // =================================================================================================
 // host side
 // =================================================================================================
@@ -257,6 +387,66 @@ int syn_cols_ring(const T* ca, const T* cd, T* out, int Nri, int Nc, int Nro, in
         default: return 1;
     }
 }
+
+#define PDWT_SWT_RING_HLENS(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20)
+
+template <typename T, int HLEN, int CPL>
+static int launch_swt_ana(const T* t, T* lo, T* hi, int Nr, int Nc, int fct, const Taps2<T>& f)
+{
+    const int strips = idiv_up(Nc, 64 * CPL);
+    const int M = Nr / fct;
+    int RO = pick_chunk(Nr, strips, HLEN);  // Nr rows in total = fct residue classes x M
+    if (RO > M) RO = M;
+    dim3 grid(idiv_up(strips, 4), fct * idiv_up(M, RO));
+    hipLaunchKernelGGL((k_swt_ana_cols_ring<T, HLEN, CPL>), grid, dim3(256), 0, stream(), t, lo, hi, Nr, Nc, fct, RO, f);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+template <typename T, int HLEN, int CPL>
+static int launch_swt_syn(const T* ca, const T* cd, T* out, int Nr, int Nc, int fct, const Taps2<T>& f)
+{
+    const int strips = idiv_up(Nc, 64 * CPL);
+    const int M = Nr / fct;
+    int RO = pick_chunk(Nr, strips, HLEN);
+    if (RO > M) RO = M;
+    dim3 grid(idiv_up(strips, 4), fct * idiv_up(M, RO));
+    hipLaunchKernelGGL((k_swt_syn_cols_ring<T, HLEN, CPL>), grid, dim3(256), 0, stream(), ca, cd, out, Nr, Nc, fct, RO, f);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
+template <typename T>
+int swt_ana_cols_ring(const T* t, T* lo, T* hi, int Nr, int Nc, int hlen, int fct, const Taps2<T>& f)
+{
+    if (Nr % fct != 0 || Nr / fct < hlen) return 1;  // the wrap must stay inside a residue class
+    constexpr int CPLV = 16 / sizeof(T) / 2;
+    const bool v = CPLV > 1 && vec_ok<T>(t, lo, hi, Nc, CPLV);
+    switch (hlen) {
+#define X(H) \
+    case H: return v ? launch_swt_ana<T, H, CPLV>(t, lo, hi, Nr, Nc, fct, f) : launch_swt_ana<T, H, 1>(t, lo, hi, Nr, Nc, fct, f);
+        PDWT_SWT_RING_HLENS(X)
+#undef X
+        default: return 1;
+    }
+}
+template <typename T>
+int swt_syn_cols_ring(const T* ca, const T* cd, T* out, int Nr, int Nc, int hlen, int fct, const Taps2<T>& f)
+{
+    if (Nr % fct != 0 || Nr / fct < hlen) return 1;
+    constexpr int CPLV = 16 / sizeof(T) / 2;
+    const bool v = CPLV > 1 && vec_ok<T>(ca, cd, out, Nc, CPLV);
+    switch (hlen) {
+#define X(H) \
+    case H: return v ? launch_swt_syn<T, H, CPLV>(ca, cd, out, Nr, Nc, fct, f) : launch_swt_syn<T, H, 1>(ca, cd, out, Nr, Nc, fct, f);
+        PDWT_SWT_RING_HLENS(X)
+#undef X
+        default: return 1;
+    }
+}
+template int swt_ana_cols_ring<float>(const float*, float*, float*, int, int, int, int, const Taps2<float>&);
+template int swt_ana_cols_ring<double>(const double*, double*, double*, int, int, int, int, const Taps2<double>&);
+template int swt_syn_cols_ring<float>(const float*, const float*, float*, int, int, int, int, const Taps2<float>&);
+template int swt_syn_cols_ring<double>(const double*, const double*, double*, int, int, int, int, const Taps2<double>&);
 
 template int ana_cols_ring<float>(const float*, float*, float*, int, int, int, const Taps2<float>&);
 template int ana_cols_ring<double>(const double*, double*, double*, int, int, int, const Taps2<double>&);

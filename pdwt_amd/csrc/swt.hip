@@ -6,6 +6,9 @@
 // would need an (hlen-1)*f halo in BOTH directions (208 samples at level 5 of db7), so each level is
 // two streaming passes whose dilated taps are served by L1/L2: x stays the lane axis, so every tap
 // is a fully coalesced 256-byte row segment; the column pass never strides a wave across rows.
+#include <type_traits>
+
+#include "cols_ring.hpp"
 #include "common.hpp"
 
 namespace pdwt {
@@ -123,6 +126,143 @@ __global__ __launch_bounds__(kSwtThreads) void k_swt_syn_rows(const T* __restric
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Row passes with the whole row resident in LDS (explicit periodic halo), persistent workgroups.
+// The direct kernels above read every dilated tap from global memory (hlen L1/L2 round trips per output);
+// here a row is staged once with 16-byte loads and each tap of a 4-output group is ONE aligned ds_read_b128
+// (tap spacing f >= 4 keeps x - c*f + f*j 16-byte aligned; lanes are 16 bytes apart: conflict-free).
+// Levels with f < 4 use one output per lane-iteration (conflict-free 4-byte reads).
+//   SYN = false : in -> lo, hi                 (src/separable.cu:409-448, centre (hlen/2-1)*f)
+//   SYN = true  : a, d -> out = a*IL/2 + d*IH/2 (src/separable.cu:593-626, centre (hlen/2)*f; taps pre-halved)
+// -------------------------------------------------------------------------------------------------
+template <int I, int N, typename F>
+__device__ __forceinline__ void sw_for_impl(F&& fn)
+{
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        sw_for_impl<I + 1, N>(fn);
+    }
+}
+template <int N, typename F>
+__device__ __forceinline__ void sw_for(F&& fn) { sw_for_impl<0, N>(fn); }
+
+__device__ __forceinline__ void swt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T> struct SwV;
+template <> struct SwV<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
+template <> struct SwV<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int N = 2; };
+
+template <typename T, int HLEN, bool SYN>
+__global__ __launch_bounds__(256) void k_swt_rows_lds(const T* __restrict__ a, const T* __restrict__ d, T* __restrict__ o1, T* __restrict__ o2,
+                                                       int Nr, int Nc, int fct, int HL, int HR, Taps2<T> f)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using V = typename SwV<T>::type;
+    constexpr int NV = SwV<T>::N;
+    constexpr int C = SYN ? HLEN / 2 : HLEN / 2 - 1;
+    const int co = C * fct;
+    const int pitch = HL + Nc + HR;  // elements; HL, Nc, HR are multiples of NV
+    T* ra = reinterpret_cast<T*>(smem) + HL;
+    T* rd = ra + pitch;  // SYN only
+    const int nchunks = Nc / NV;
+    for (int row = blockIdx.x; row < Nr; row += gridDim.x) {
+        const V* ga = reinterpret_cast<const V*>(a + (size_t)row * Nc);
+        const V* gd = reinterpret_cast<const V*>(SYN ? d + (size_t)row * Nc : a);
+        for (int i = threadIdx.x; i < nchunks; i += 256) {
+            reinterpret_cast<V*>(ra)[i] = ga[i];
+            if (SYN) reinterpret_cast<V*>(rd)[i] = gd[i];
+        }
+        swt_lds_barrier();
+        for (int k = threadIdx.x; k < HL + HR; k += 256) {
+            const int idx = k < HL ? k - HL : Nc + (k - HL);
+            const int src = wrap_per(idx, Nc);
+            ra[idx] = ra[src];
+            if (SYN) rd[idx] = rd[src];
+        }
+        swt_lds_barrier();
+        if (fct >= NV) {
+            for (int g = threadIdx.x; g < nchunks; g += 256) {
+                const T* pa = ra + g * NV - co;
+                const T* pd = rd + g * NV - co;
+                T s1[NV], s2[NV];
+#pragma unroll
+                for (int q = 0; q < NV; q++) s1[q] = s2[q] = T(0);
+                sw_for<HLEN>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    const T fa = f.a[HLEN - 1 - j], fb = f.b[HLEN - 1 - j];
+                    const V va = *reinterpret_cast<const V*>(pa + fct * j);
+                    if (SYN) {
+                        const V vd = *reinterpret_cast<const V*>(pd + fct * j);
+#pragma unroll
+                        for (int q = 0; q < NV; q++) {
+                            s1[q] = fma_t(va[q], fa, s1[q]);
+                            s2[q] = fma_t(vd[q], fb, s2[q]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < NV; q++) {
+                            s1[q] = fma_t(va[q], fa, s1[q]);
+                            s2[q] = fma_t(va[q], fb, s2[q]);
+                        }
+                    }
+                });
+                V r1, r2;
+#pragma unroll
+                for (int q = 0; q < NV; q++) {
+                    r1[q] = SYN ? s1[q] + s2[q] : s1[q];
+                    r2[q] = s2[q];
+                }
+                reinterpret_cast<V*>(o1 + (size_t)row * Nc)[g] = r1;
+                if (!SYN) reinterpret_cast<V*>(o2 + (size_t)row * Nc)[g] = r2;
+            }
+        } else {
+            for (int x = threadIdx.x; x < Nc; x += 256) {
+                const T* pa = ra + x - co;
+                const T* pd = rd + x - co;
+                T s1 = 0, s2 = 0;
+                sw_for<HLEN>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    const T va = pa[fct * j];
+                    s1 = fma_t(va, f.a[HLEN - 1 - j], s1);
+                    s2 = fma_t(SYN ? pd[fct * j] : va, f.b[HLEN - 1 - j], s2);
+                });
+                o1[(size_t)row * Nc + x] = SYN ? s1 + s2 : s1;
+                if (!SYN) o2[(size_t)row * Nc + x] = s2;
+            }
+        }
+        swt_lds_barrier();  // the row buffers are rewritten by the next iteration
+    }
+}
+
+#define PDWT_SWT_ROWS_HLENS(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20)
+
+// returns PDWT_OK when launched, 1 when the geometry is outside this path
+template <typename T, bool SYN>
+static int swt_rows_lds(const T* a, const T* d, T* o1, T* o2, int Nr, int Nc, int hlen, int fct, const Taps2<T>& f, int ktimer_id)
+{
+    constexpr int NV = SwV<T>::N;
+    if (Nc % NV != 0 || (((uintptr_t)a | (uintptr_t)d | (uintptr_t)o1 | (uintptr_t)o2) & 15) != 0) return 1;
+    const int C = SYN ? hlen / 2 : hlen / 2 - 1;
+    auto up = [](int v) { return ((v + NV - 1) / NV) * NV; };
+    const int HL = up(C * fct), HR = up((hlen - 1 - C) * fct + NV);
+    if (HL > Nc || HR > Nc) return 1;
+    const size_t lds = (size_t)(SYN ? 2 : 1) * (HL + Nc + HR) * sizeof(T);
+    if (lds > 64 * 1024) return 1;
+    void (*k)(const T*, const T*, T*, T*, int, int, int, int, int, Taps2<T>) = nullptr;
+    switch (hlen) {
+#define X(H) case H: k = k_swt_rows_lds<T, H, SYN>; break;
+        PDWT_SWT_ROWS_HLENS(X)
+#undef X
+        default: return 1;
+    }
+    const int per_cu = (int)((160 * 1024) / (lds + 256)) > 8 ? 8 : (int)((160 * 1024) / (lds + 256));
+    const int grid = Nr < 256 * per_cu ? Nr : 256 * per_cu;
+    KTimer kt(ktimer_id);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, stream(), a, d, o1, o2, Nr, Nc, fct, HL, HR, f);
+    PDWT_HIP_TRY(hipGetLastError());
+    return PDWT_OK;
+}
+
 #define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
 
 static dim3 swt_grid(int Nr, int Nc) { return dim3(idiv_up(Nc, 64), idiv_up(Nr, 4 * kSwtRows)); }
@@ -148,15 +288,25 @@ static int forward_swt(T* d_image, T** c, T* d_tmp, pdwt_info w, const typename 
     const dim3 grid = swt_grid(w.Nr, w.Nc);
     for (int lev = 0; lev < w.nlevels; lev++) {
         {
-            KTimer kt(K_SWT_ANA_ROWS);
-            hipLaunchKernelGGL(k_swt_ana_rows<T>, grid, dim3(kSwtThreads), 0, stream(), in, t1, t2, w.Nr, w.Nc, w.hlen, 1 << lev, f);
-            PDWT_CHECK_LAUNCH();
+            int rr = swt_rows_lds<T, false>(in, in, t1, t2, w.Nr, w.Nc, w.hlen, 1 << lev, f, K_SWT_ANA_ROWS);
+            if (rr < 0) return rr;
+            if (rr > 0) {
+                KTimer kt(K_SWT_ANA_ROWS);
+                hipLaunchKernelGGL(k_swt_ana_rows<T>, grid, dim3(kSwtThreads), 0, stream(), in, t1, t2, w.Nr, w.Nc, w.hlen, 1 << lev, f);
+                PDWT_CHECK_LAUNCH();
+            }
         }
         {
             KTimer kt(K_SWT_ANA_COLS);
-            hipLaunchKernelGGL(k_swt_ana_cols<T>, grid, dim3(kSwtThreads), 0, stream(), (const T*)t1, (const T*)t2, c[0], c[3 * lev + 1],
-                               c[3 * lev + 2], c[3 * lev + 3], w.Nr, w.Nc, w.hlen, 1 << lev, f);
-            PDWT_CHECK_LAUNCH();
+            // register-ring form per residue class (cols_ring.hip); direct dilated-tap kernel when f does not divide Nr
+            int rr = swt_ana_cols_ring<T>(t1, c[0], c[3 * lev + 1], w.Nr, w.Nc, w.hlen, 1 << lev, f);
+            if (rr == PDWT_OK) rr = swt_ana_cols_ring<T>(t2, c[3 * lev + 2], c[3 * lev + 3], w.Nr, w.Nc, w.hlen, 1 << lev, f);
+            if (rr < 0) return rr;
+            if (rr > 0) {
+                hipLaunchKernelGGL(k_swt_ana_cols<T>, grid, dim3(kSwtThreads), 0, stream(), (const T*)t1, (const T*)t2, c[0], c[3 * lev + 1],
+                                   c[3 * lev + 2], c[3 * lev + 3], w.Nr, w.Nc, w.hlen, 1 << lev, f);
+                PDWT_CHECK_LAUNCH();
+            }
         }
         in = c[0];  // stream order makes the read-then-overwrite of band 0 safe (two separate launches)
     }
@@ -176,16 +326,25 @@ static int inverse_swt(T* d_image, T** c, T* d_tmp, pdwt_info w, const typename 
     for (int i = w.nlevels - 1; i >= 0; i--) {
         {
             KTimer kt(K_SWT_SYN_COLS);
-            hipLaunchKernelGGL(k_swt_syn_cols<T>, grid, dim3(kSwtThreads), 0, stream(), (const T*)c[0], (const T*)c[3 * i + 1],
-                               (const T*)c[3 * i + 2], (const T*)c[3 * i + 3], t1, t2, w.Nr, w.Nc, w.hlen, 1 << i, f);
-            PDWT_CHECK_LAUNCH();
+            int rr = swt_syn_cols_ring<T>(c[0], c[3 * i + 1], t1, w.Nr, w.Nc, w.hlen, 1 << i, f);
+            if (rr == PDWT_OK) rr = swt_syn_cols_ring<T>(c[3 * i + 2], c[3 * i + 3], t2, w.Nr, w.Nc, w.hlen, 1 << i, f);
+            if (rr < 0) return rr;
+            if (rr > 0) {
+                hipLaunchKernelGGL(k_swt_syn_cols<T>, grid, dim3(kSwtThreads), 0, stream(), (const T*)c[0], (const T*)c[3 * i + 1],
+                                   (const T*)c[3 * i + 2], (const T*)c[3 * i + 3], t1, t2, w.Nr, w.Nc, w.hlen, 1 << i, f);
+                PDWT_CHECK_LAUNCH();
+            }
         }
         {
-            KTimer kt(K_SWT_SYN_ROWS);
             T* out = (i == 0) ? d_image : c[0];
-            hipLaunchKernelGGL(k_swt_syn_rows<T>, grid, dim3(kSwtThreads), 0, stream(), (const T*)t1, (const T*)t2, out, w.Nr, w.Nc, w.hlen,
-                               1 << i, f);
-            PDWT_CHECK_LAUNCH();
+            int rr = swt_rows_lds<T, true>(t1, t2, out, out, w.Nr, w.Nc, w.hlen, 1 << i, f, K_SWT_SYN_ROWS);
+            if (rr < 0) return rr;
+            if (rr > 0) {
+                KTimer kt(K_SWT_SYN_ROWS);
+                hipLaunchKernelGGL(k_swt_syn_rows<T>, grid, dim3(kSwtThreads), 0, stream(), (const T*)t1, (const T*)t2, out, w.Nr, w.Nc, w.hlen,
+                                   1 << i, f);
+                PDWT_CHECK_LAUNCH();
+            }
         }
     }
     return PDWT_OK;
@@ -203,9 +362,13 @@ static int forward_swt_1d(T* d_image, T** c, T* d_tmp, pdwt_info w, const typena
     const dim3 grid = swt_grid(w.Nr, w.Nc);
     for (int lev = 0; lev < w.nlevels; lev++) {
         T* aout = (lev == w.nlevels - 1) ? c[0] : ping[lev & 1];
-        KTimer kt(K_SWT_ANA_ROWS);
-        hipLaunchKernelGGL(k_swt_ana_rows<T>, grid, dim3(kSwtThreads), 0, stream(), in, aout, c[lev + 1], w.Nr, w.Nc, w.hlen, 1 << lev, f);
-        PDWT_CHECK_LAUNCH();
+        int rr = swt_rows_lds<T, false>(in, in, aout, c[lev + 1], w.Nr, w.Nc, w.hlen, 1 << lev, f, K_SWT_ANA_ROWS);
+        if (rr < 0) return rr;
+        if (rr > 0) {
+            KTimer kt(K_SWT_ANA_ROWS);
+            hipLaunchKernelGGL(k_swt_ana_rows<T>, grid, dim3(kSwtThreads), 0, stream(), in, aout, c[lev + 1], w.Nr, w.Nc, w.hlen, 1 << lev, f);
+            PDWT_CHECK_LAUNCH();
+        }
         in = aout;
     }
     return PDWT_OK;
@@ -223,9 +386,13 @@ static int inverse_swt_1d(T* d_image, T** c, T* d_tmp, pdwt_info w, const typena
     const dim3 grid = swt_grid(w.Nr, w.Nc);
     for (int i = w.nlevels - 1; i >= 0; i--) {
         T* out = (i == 0) ? d_image : ping[i & 1];
-        KTimer kt(K_SWT_SYN_ROWS);
-        hipLaunchKernelGGL(k_swt_syn_rows<T>, grid, dim3(kSwtThreads), 0, stream(), a, (const T*)c[i + 1], out, w.Nr, w.Nc, w.hlen, 1 << i, f);
-        PDWT_CHECK_LAUNCH();
+        int rr = swt_rows_lds<T, true>(a, (const T*)c[i + 1], out, out, w.Nr, w.Nc, w.hlen, 1 << i, f, K_SWT_SYN_ROWS);
+        if (rr < 0) return rr;
+        if (rr > 0) {
+            KTimer kt(K_SWT_SYN_ROWS);
+            hipLaunchKernelGGL(k_swt_syn_rows<T>, grid, dim3(kSwtThreads), 0, stream(), a, (const T*)c[i + 1], out, w.Nr, w.Nc, w.hlen, 1 << i, f);
+            PDWT_CHECK_LAUNCH();
+        }
         a = out;
     }
     return PDWT_OK;
