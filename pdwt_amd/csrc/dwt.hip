@@ -21,6 +21,7 @@
 #include "cols_ring.hpp"
 #include "dwt1d_fused.hpp"
 #include "dwt_stream.hpp"
+#include "dwt_tail.hpp"
 
 namespace pdwt {
 
@@ -675,6 +676,13 @@ static int forward_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typ
         in = aout;
         nr = div2(nr);
         nc = div2(nc);
+        if constexpr (sizeof(T) == 4) {
+            // all remaining (small, latency-bound) levels in ONE launch: dwt_tail.hip
+            if (lev == 0 && w.nlevels >= 3 && !force_twopass()) {
+                rc = fwd2d_tail_f32(in, c, 1, w.nlevels, nr, nc, w.hlen, f);
+                if (rc <= 0) return rc;
+            }
+        }
     }
     return PDWT_OK;
 }
@@ -695,7 +703,19 @@ static int inverse_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typ
         tNc[i] = div2(tNc[i - 1]);
     }
     const T* a = c[0];
-    for (int i = w.nlevels - 1; i >= 0; i--) {
+    int top = w.nlevels - 1;
+    if constexpr (sizeof(T) == 4) {
+        // levels nlevels-1 .. 1 (the small ones) in ONE launch -> approximation of level 0's input bands (dwt_tail.hip)
+        if (w.nlevels >= 3 && !force_twopass()) {
+            rc = inv2d_head_f32(s.ping[1], c, 1, w.nlevels, tNr[1], tNc[1], w.hlen, f);
+            if (rc < 0) return rc;
+            if (rc == PDWT_OK) {
+                a = s.ping[1];
+                top = 0;
+            }
+        }
+    }
+    for (int i = top; i >= 0; i--) {
         T* out = (i == 0) ? d_image : s.ping[i & 1];
         rc = level_inv2d(a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], out, s.t1, s.t2, tNr[i + 1], tNc[i + 1], tNr[i], tNc[i], w.hlen, f);
         if (rc != PDWT_OK) return rc;
@@ -766,6 +786,10 @@ int pdwt_debug_set(const char* key, int value)
     }
     if (key && !strcmp(key, "tiled_cols")) {  // 1: LDS-tiled column kernels instead of the register-ring ones
         g_tiled_cols = value ? 1 : 0;
+        return PDWT_OK;
+    }
+    if (key && !strcmp(key, "tail")) {  // 0: one launch per level instead of the fused small-level launches
+        tail_set_enabled(value);
         return PDWT_OK;
     }
     if (key && !strcmp(key, "stream")) {  // 0: use the LDS-tiled fused kernels instead of the streaming ones

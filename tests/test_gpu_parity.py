@@ -340,3 +340,26 @@ def test_dropin_demo_program(tmp_path):
         assert band_err(rec, O.get_image()) <= TOL[np.dtype(dt)]
         vals = [float(l.split("=")[1]) for l in r.stdout.splitlines() if "L1 =" in l]
         assert abs(vals[0] - n_before) <= 2e-6 * n_before and abs(vals[1] - n_after) <= 2e-6 * n_after
+
+
+@pytest.mark.parametrize("wname", ["db2", "db4", "db7", "sym8"])
+def test_fused_small_levels_equal_per_level(wname):
+    """dwt_tail.hip (opt-in: levels >= 2 in one launch per direction) is the same arithmetic as one launch per level."""
+    rs = np.random.RandomState(23)
+    L = pdwt_amd.hip()
+    for shape, levels in (((512, 512), 3), ((1024, 512), 4), ((256, 768), 3)):
+        x = rs.uniform(0, 255, shape).astype(np.float32)
+        res = []
+        for tail in (1, 0):
+            assert L.pdwt_debug_set(b"tail", tail) == 0
+            try:
+                W = pdwt_amd.Wavelets(x, wname, levels)
+                W.forward()
+                c = W.coeffs
+                W.inverse()
+                res.append((c, W.get_image()))
+            finally:
+                L.pdwt_debug_set(b"tail", 0)  # opt-in path: back to the default (off)
+        for a, b in zip(res[0][0], res[1][0]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(res[0][1], res[1][1])
