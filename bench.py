@@ -76,6 +76,13 @@ def algorithmic_bytes(cfg, levels_eff):
             per_kernel = {"fwd2d_fused": 2 * n * sz, "inv2d_fused": 2 * n * sz,
                           "ana_rows": 2 * n * sz, "ana_cols": 2 * n * sz, "syn_cols": 2 * n * sz, "syn_rows": 2 * n * sz,
                           "haar2d_fwd": 2 * n * sz, "haar2d_inv": 2 * n * sz}
+            # float32 path: levels (1,2) run as ONE cascade launch (dwt_casc.hip) that reads the N-element input once and
+            # writes 3N/4 + 4N/16 = N coefficients (the level-1 approximation never goes to memory); the remaining
+            # levels are one launch each
+            if sz == 4 and L >= 2:
+                n12 = N + ((cfg["Nr"] + 1) // 2) * ((cfg["Nc"] + 1) // 2)
+                per_kernel.update({"fwd2d_casc": 2 * N * sz, "inv2d_casc": 2 * N * sz,
+                                   "fwd2d_fused|casc": 2 * (n - n12) * sz, "inv2d_fused|casc": 2 * (n - n12) * sz})
         else:
             # batched 1D runs ALL levels in one launch (dwt1d_fused.hip): read the batch once, write every band once
             per_kernel = {"ana_rows": 2 * N * sz, "syn_rows": 2 * N * sz, "haar1d_fwd": 2 * n * sz, "haar1d_inv": 2 * n * sz}
@@ -248,6 +255,9 @@ def main():
                                                                avg_us=ms.value * 1e3 / n.value)
         L.pdwt_ktime_enable(0)
         L.pdwt_ktime_reset()
+        for d in ("fwd2d", "inv2d"):  # single-level launches cover only the levels the cascade launch did not
+            if d + "_casc" in kernels and d + "_fused|casc" in per_kernel_bytes:
+                per_kernel_bytes[d + "_fused"] = per_kernel_bytes[d + "_fused|casc"]
         cand = [k for k in kernels if k in per_kernel_bytes]
         if cand:
             dom = max(cand, key=lambda k: kernels[k]["us_per_step"])

@@ -42,6 +42,8 @@ enum KernelId {
     K_SOFT_THRESH,
     K_ABS_SUM,
     K_ABS_SUM_FINAL,
+    K_FWD2D_CASC,  // two levels per launch (dwt_casc.hip)
+    K_INV2D_CASC,
     K_COUNT
 };
 

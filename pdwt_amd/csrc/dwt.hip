@@ -21,6 +21,7 @@
 #include "cols_ring.hpp"
 #include "dwt1d_fused.hpp"
 #include "dwt_stream.hpp"
+#include "dwt_casc.hpp"
 #include "dwt_tail.hpp"
 
 namespace pdwt {
@@ -669,15 +670,35 @@ static int forward_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typ
     Scratch<T> s(d_tmp, w.Nr, w.Nc, 2);
     const T* in = d_image;
     int nr = w.Nr, nc = w.Nc;
+    int pp = 0;  // scratch buffer the next intermediate approximation goes to (never the one `in` lives in)
     for (int lev = 0; lev < w.nlevels; lev++) {
-        T* aout = (lev == w.nlevels - 1) ? c[0] : s.ping[lev & 1];
+        if constexpr (sizeof(T) == 4) {
+            // two levels in one launch, the approximation between them stays in registers (dwt_casc.hip)
+            if (lev + 1 < w.nlevels && !force_twopass()) {
+                T* a2 = (lev + 2 == w.nlevels) ? c[0] : s.ping[pp];
+                float* trash = ((size_t)nr * div2(nc) >= kStreamTrashFloats) ? (float*)s.t1 : nullptr;
+                rc = fwd2d_casc_f32(in, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], a2, c[3 * lev + 4], c[3 * lev + 5], c[3 * lev + 6],
+                                    trash, nr, nc, w.hlen, f);
+                if (rc < 0) return rc;
+                if (rc == PDWT_OK) {
+                    in = a2;
+                    pp ^= 1;
+                    nr = div2(div2(nr));
+                    nc = div2(div2(nc));
+                    lev++;
+                    continue;
+                }
+            }
+        }
+        T* aout = (lev == w.nlevels - 1) ? c[0] : s.ping[pp];
         rc = level_fwd2d(in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], s.t1, s.t2, nr, nc, w.hlen, f);
         if (rc != PDWT_OK) return rc;
         in = aout;
+        pp ^= 1;
         nr = div2(nr);
         nc = div2(nc);
         if constexpr (sizeof(T) == 4) {
-            // all remaining (small, latency-bound) levels in ONE launch: dwt_tail.hip
+            // opt-in: all remaining (small, latency-bound) levels in ONE launch (dwt_tail.hip)
             if (lev == 0 && w.nlevels >= 3 && !force_twopass()) {
                 rc = fwd2d_tail_f32(in, c, 1, w.nlevels, nr, nc, w.hlen, f);
                 if (rc <= 0) return rc;
@@ -715,11 +736,30 @@ static int inverse_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typ
             }
         }
     }
+    int pp = (a == s.ping[0]) ? 1 : 0;  // scratch buffer the next intermediate approximation goes to (never the one `a` lives in)
     for (int i = top; i >= 0; i--) {
-        T* out = (i == 0) ? d_image : s.ping[i & 1];
+        if constexpr (sizeof(T) == 4) {
+            // levels i and i-1 in one launch, the approximation between them stays in registers (dwt_casc.hip);
+            // pairs are (1,0), (3,2), ... so that the finest -- most expensive -- level is always in a pair
+            if ((i & 1) && !force_twopass()) {
+                T* out = (i == 1) ? d_image : s.ping[pp];
+                float* trash = ((size_t)tNr[i - 1] * tNc[i] >= kStreamTrashFloats) ? (float*)s.t1 : nullptr;
+                rc = inv2d_casc_f32(a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], c[3 * i - 2], c[3 * i - 1], c[3 * i], out, trash, tNr[i - 1],
+                                    tNc[i - 1], w.hlen, f);
+                if (rc < 0) return rc;
+                if (rc == PDWT_OK) {
+                    a = out;
+                    pp ^= 1;
+                    i--;
+                    continue;
+                }
+            }
+        }
+        T* out = (i == 0) ? d_image : s.ping[pp];
         rc = level_inv2d(a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], out, s.t1, s.t2, tNr[i + 1], tNc[i + 1], tNr[i], tNc[i], w.hlen, f);
         if (rc != PDWT_OK) return rc;
         a = out;
+        pp ^= 1;
     }
     return PDWT_OK;
 }
@@ -786,6 +826,10 @@ int pdwt_debug_set(const char* key, int value)
     }
     if (key && !strcmp(key, "tiled_cols")) {  // 1: LDS-tiled column kernels instead of the register-ring ones
         g_tiled_cols = value ? 1 : 0;
+        return PDWT_OK;
+    }
+    if (key && !strcmp(key, "casc")) {  // 0: one launch per level instead of the two-level cascade launches
+        pdwt::casc_set_enabled(value);
         return PDWT_OK;
     }
     if (key && !strcmp(key, "tail")) {  // 0: one launch per level instead of the fused small-level launches

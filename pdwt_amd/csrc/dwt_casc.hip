@@ -1,0 +1,605 @@
+// dwt_casc.hip -- TWO levels of the 2D DWT per launch, float32, streaming form ("cascade").
+//
+// After the level kernels of dwt_stream.hip reached the copy roofline, what is left of a multi-level
+// transform is (a) the approximation of level l written to HBM and read back by level l+1 and (b) the
+// launch of level l+1, which is latency-bound at its size (profiles/: 8.5-10 us for 32 MB).  Here a wave
+// that streams down its strip of level l feeds the A row it has just produced straight into a SECOND
+// register ring and emits level l+1 from registers:
+//   lane = 4 input columns -> 2 columns of level l (A1,H1,V1,D1) -> 1 column of level l+1 (A2,H2,V2,D2)
+//   every 2 input rows: one row of H1,V1,D1 (8-byte stores); the A1 pair goes through the level-(l+1) row
+//   pass (halo from neighbouring lanes by DPP, as for the input) into ring2;
+//   every 4 input rows: one row of A2,H2,V2,D2 (4-byte stores).
+// Halo: NB1 lanes (input) + NB2 lanes (A1) per side -> 58 producing lanes of 64 for hlen 8; vertically a
+// chunk of R2 level-(l+1) rows recomputes hlen-2 rows of A1 (and reads 3(hlen-2) extra input rows, L2 hits).
+// The loop is branch-free: every store is always issued (halo lanes, rows outside the chunk's own range
+// and the ring warm-up go to a trash slot), so the hand-counted s_waitcnt pipeline of dwt_stream.hip
+// carries over with per-position constants (casc_after).
+// Arithmetic per sample = the single-level kernels' (row pass then column pass, taps ascending, one FMA
+// per tap), so the result is bit-identical to running the two levels separately.
+// Reference code replaced: two iterations of the level loop of w_forward_separable / w_inverse_separable
+// (src/separable.cu:179-209, 332-364) with their four kernels each.
+#include "dwt_casc.hpp"
+
+#include "dwt_stream.hpp"
+#include "stream_dev.hpp"
+
+namespace pdwt {
+
+template <int HLEN>
+struct CascGeom {
+    static constexpr int C = HLEN / 2 - 1;                      // halo samples per side, both levels
+    static constexpr int NB1 = C > 0 ? (C + 3) / 4 : 0;         // halo lanes for the input window (4 columns per lane)
+    static constexpr int NB2 = C > 0 ? (C + 1) / 2 : 0;         // halo lanes for the A1 window (2 columns per lane)
+    static constexpr int NBT = NB1 + NB2;                       // lanes per side that produce no output
+    static constexpr int WIN1 = 4 * (2 * NB1 + 1);
+    static constexpr int WIN2 = 2 * (2 * NB2 + 1);
+    static constexpr int MAXVL = 64 - 2 * NBT;
+};
+
+struct CascMap {
+    int cpx;     // chunk rows per XCD (all 8 XCDs get the same number)
+    int strips;  // strips (= waves) per chunk row
+};
+struct CascBands {
+    float *H1, *V1, *D1, *A2, *H2, *V2, *D2;
+};
+
+// forward: VMEM instructions a wave issues per A1 row `p` of a super-body after that row's two loads
+constexpr int casc_fwd_stores(int p) { return 3 + 4 * (p & 1); }
+// ... and between the second load issued at position p and the next use of those registers
+// (position p + DIST, DIST = A1 rows of prefetch distance)
+template <int DIST>
+constexpr int casc_fwd_after(int p)
+{
+    int n = casc_fwd_stores(p);
+    for (int k = 1; k < DIST; k++) n += 2 + casc_fwd_stores(p + k);
+    return n;
+}
+
+// PF = prefetch distance in bodies of HLEN input rows (1: HLEN KiB in flight per wave, 2: 2*HLEN KiB)
+template <int HLEN, int PF>
+__global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in, CascBands b, int Nr, int Nc, int VL,
+                                                     float* __restrict__ trash, CascMap cm, TapsLH f)
+{
+    using G = CascGeom<HLEN>;
+    constexpr int C = G::C, NB1 = G::NB1, NB2 = G::NB2, NBT = G::NBT, WIN1 = G::WIN1, WIN2 = G::WIN2;
+    // wave -> (chunk row, strip): XCD x (= blockIdx % 8, private L2) owns the contiguous band of chunk rows
+    // [x*cpx, (x+1)*cpx) and its waves walk that band strip by strip, so neighbours in space are neighbours in time
+    const int lane = threadIdx.x & 63;
+    const int xcd = blockIdx.x & 7;
+    const int wi = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    if (wi >= cm.cpx * cm.strips) return;
+    const int cy = xcd * cm.cpx + wi / cm.strips;
+    const int strip = wi % cm.strips;
+    const int xs = strip * VL * 4;  // first input column this strip produces outputs for
+    const int Nc2 = Nc >> 1, Nr4 = Nr >> 2, Nc4 = Nc >> 2;
+    const int nchunks = 8 * cm.cpx;
+    const int j0 = (int)(((long long)cy * Nr4) / nchunks);  // level-2 rows [j0, j1) of the chunk
+    const int rows2 = (int)(((long long)(cy + 1) * Nr4) / nchunks) - j0;
+    if (rows2 <= 0) return;
+    const int x = xs + 4 * (lane - NBT);
+    const bool valid = (lane >= NBT) && (lane < NBT + VL) && (x < Nc);
+    const int xo = wrapi(x, Nc);
+    const int yb = 4 * j0 - 3 * C;           // input row of chunk-local row 0 (A1 row n <-> input rows 2n .. 2n+HLEN-1)
+    const int NA1 = 2 * rows2 + HLEN - 2;    // A1 rows the chunk computes; n in [C, C+2*rows2) are its own
+
+    v2f ring[HLEN][2];  // level 1: (lo,hi) row-pass results of the last HLEN input rows, 2 columns
+    v2f ring2[HLEN];    // level 2: (lo,hi) row-pass results of the last HLEN A1 rows, 1 column
+#pragma unroll
+    for (int k = 0; k < HLEN; k++) ring2[k] = v2f{0.f, 0.f};
+
+    const float* const lbase = in + xo;
+    auto rowptr = [&](int r) { return lbase + (size_t)wrap1(yb + r, Nr) * Nc; };
+
+    auto row_pass1 = [&](const v4f& v, v2f (&lh)[2]) {
+        float w[WIN1];
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[NB1 * 4 + q] = v[q];
+#pragma unroll
+        for (int k = 0; k < NB1; k++) {
+            const int dl = (NB1 - 1 - k) * 4, sl = (NB1 - k) * 4, dr = (NB1 + 1 + k) * 4, sr = (NB1 + k) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                w[dl + q] = dpp_shr1(w[sl + q]);
+                w[dr + q] = dpp_shl1(w[sr + q]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            v2f acc = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < HLEN; j++) acc = pk_fma(splat(w[NB1 * 4 - C + 2 * p + j]), f.t[HLEN - 1 - j], acc);
+            lh[p] = acc;
+        }
+    };
+    auto row_pass2 = [&](float a0, float a1, v2f& lh) {
+        float w[WIN2];
+        w[NB2 * 2] = a0;
+        w[NB2 * 2 + 1] = a1;
+#pragma unroll
+        for (int k = 0; k < NB2; k++) {
+            const int dl = (NB2 - 1 - k) * 2, sl = (NB2 - k) * 2, dr = (NB2 + 1 + k) * 2, sr = (NB2 + k) * 2;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                w[dl + q] = dpp_shr1(w[sl + q]);
+                w[dr + q] = dpp_shl1(w[sr + q]);
+            }
+        }
+        v2f acc = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < HLEN; j++) acc = pk_fma(splat(w[NB2 * 2 - C + j]), f.t[HLEN - 1 - j], acc);
+        lh = acc;
+    };
+
+    // ring prologue rows 0..HLEN-3 and the first body's rows, issued together
+    constexpr int NV = PF * HLEN;   // row registers = input rows in flight
+    constexpr int DIST = NV / 2;    // prefetch distance in A1 rows
+    static_assert(casc_fwd_after<DIST>(1) <= 63, "vmcnt is a 6-bit counter");
+    v4f v[NV];
+    {
+        v4f pv[HLEN > 2 ? HLEN - 2 : 1];
+#pragma unroll
+        for (int r = 0; r < HLEN - 2; r++) pv[r] = *reinterpret_cast<const v4f*>(rowptr(r));
+#pragma unroll
+        for (int u = 0; u < NV; u++) v[u] = *reinterpret_cast<const v4f*>(rowptr(HLEN - 2 + u));
+        static_for<HLEN - 2>([&](auto Rr) {
+            constexpr int r = decltype(Rr)::value;
+            row_pass1(pv[r], ring[r]);
+        });
+    }
+
+    float* const tr = trash + (size_t)(blockIdx.x & 255) * 1024 + (threadIdx.x >> 6) * 256 + lane * 2;
+    const size_t ocol1 = (size_t)(x >> 1), ocol2 = (size_t)(x >> 2);
+    static_for<NV>([&](auto K) { asm_drain1(v[decltype(K)::value]); });
+    auto a1_row = [&](auto A, int sb) {
+            constexpr int a = decltype(A)::value;  // A1 row within the super-body
+            constexpr int u = a % (HLEN / 2);
+            constexpr int s0 = (2 * u + HLEN - 2) % HLEN, s1 = (2 * u + HLEN - 1) % HLEN;
+            const int n = sb * HLEN + a;  // chunk-local A1 row
+            constexpr int r0 = (2 * a) % NV, r1 = r0 + 1;
+            // v[r0], v[r1] were loaded DIST A1 rows ago, at position (a - DIST) mod HLEN
+            asm_wait2<casc_fwd_after<DIST>((a + HLEN - DIST) % HLEN)>(v[r0], v[r1]);
+            row_pass1(v[r0], ring[s0]);
+            row_pass1(v[r1], ring[s1]);
+            const int rn = 2 * n + HLEN - 2 + NV;  // the rows these registers hold DIST A1 rows ahead
+            asm_load(v[r0], rowptr(rn));
+            asm_load(v[r1], rowptr(rn + 1));
+            // level-1 column pass
+            v2f ah[2], vd[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) ah[p] = vd[p] = v2f{0.f, 0.f};
+            static_for<HLEN>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                constexpr int s = (2 * u + j) % HLEN;
+                const v2f t = f.t[HLEN - 1 - j];
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    ah[p] = pk_fma(splat(ring[s][p].x), t, ah[p]);
+                    vd[p] = pk_fma(splat(ring[s][p].y), t, vd[p]);
+                }
+            });
+            {
+                const bool st = valid && (n >= C) && (n < C + 2 * rows2);
+                const size_t o = (size_t)(2 * j0 + n - C) * Nc2 + ocol1;
+                asm_store(st ? b.H1 + o : tr, v2f{ah[0].y, ah[1].y});
+                asm_store(st ? b.V1 + o : tr + 128, v2f{vd[0].x, vd[1].x});
+                asm_store(st ? b.D1 + o : tr, v2f{vd[0].y, vd[1].y});
+            }
+            // level-2 row pass on the A1 pair; ring2 slot = n % HLEN = a
+            row_pass2(ah[0].x, ah[1].x, ring2[a]);
+            if constexpr (a & 1) {
+                // A1 rows n-HLEN+1 .. n complete the window of level-2 row (n-(HLEN-1))/2
+                v2f ah2 = {0.f, 0.f}, vd2 = {0.f, 0.f};
+                static_for<HLEN>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    constexpr int s = (a + 1 + j) % HLEN;
+                    const v2f t = f.t[HLEN - 1 - j];
+                    ah2 = pk_fma(splat(ring2[s].x), t, ah2);
+                    vd2 = pk_fma(splat(ring2[s].y), t, vd2);
+                });
+                const int jl = (n - (HLEN - 1)) >> 1;
+                const bool st = valid && (n >= HLEN - 1) && (jl < rows2);
+                const size_t o = (size_t)(j0 + jl) * Nc4 + ocol2;
+                asm_store(st ? b.A2 + o : tr, ah2.x);
+                asm_store(st ? b.H2 + o : tr + 128, ah2.y);
+                asm_store(st ? b.V2 + o : tr + 1, vd2.x);
+                asm_store(st ? b.D2 + o : tr + 129, vd2.y);
+            }
+    };
+    for (int sb = 0;; sb++) {
+        static_for<HLEN / 2>([&](auto U) { a1_row(std::integral_constant<int, decltype(U)::value>{}, sb); });
+        if (sb * HLEN + HLEN / 2 >= NA1) break;
+        static_for<HLEN / 2>([&](auto U) { a1_row(std::integral_constant<int, decltype(U)::value + HLEN / 2>{}, sb); });
+        if (sb * HLEN + HLEN >= NA1) break;
+    }
+    static_for<NV>([&](auto K) { asm_drain1(v[decltype(K)::value]); });
+}
+
+// =================================================================================================
+// inverse: levels l+1 and l in one launch
+// =================================================================================================
+// lane = 1 coefficient column of level l+1 -> 2 columns of A_l (which never goes to memory) = the lane's 2
+// coefficient columns of level l -> 4 output columns.  One STEP = one new coefficient row of level l+1:
+//   level-(l+1) column synthesis for both tap parities -> DPP halo of (t1,t2) -> row synthesis -> two rows of
+//   A_l; each of them enters the level-l ring together with the H,V,D row loaded from memory and yields two
+//   output rows (column synthesis, DPP halo, row synthesis, one 16-byte store each) -- the arithmetic of
+//   k_inv2d_stream, twice.
+// A super-body = H2 steps brings both rings back to slot 0, so every slot is a compile-time constant.  The
+// row registers of a step are re-issued for the same step ONE SUPER-BODY AHEAD; all loads/stores are inline
+// asm with exact s_waitcnt counts (14 VMEM per step: 4 loads, then per A_l row 3 loads + 2 stores).
+// The recomputed halo lands on the coarse level (4x less data), so it is cheap in this direction.
+template <int HLEN>
+struct CascInvGeom {
+    static constexpr int H2 = HLEN / 2;
+    static constexpr int C = H2 / 2;
+    static constexpr int SHIFT = (H2 & 1) ? 0 : 1;
+    static constexpr int NB1 = C > 0 ? (C + 1) / 2 : 0;  // halo lanes, level l (2 coefficient columns per lane)
+    static constexpr int NB2 = C;                         // halo lanes, level l+1 (1 column per lane)
+    static constexpr int NBT = NB1 + NB2;
+    static constexpr int WIN1 = 2 * (2 * NB1 + 1);
+    static constexpr int WIN2 = 2 * NB2 + 1;
+    static constexpr int MAXVL = 64 - 2 * NBT;
+    // chunks start at level-l coefficient rows of this parity so that the first A_l row a chunk needs
+    // (ya - C) is the first of the pair a level-(l+1) step produces (rows 2P-SHIFT, 2P+1-SHIFT)
+    static constexpr int BASE = (C - SHIFT) & 1;
+    static constexpr int VM_SB = H2 * (4 + 2 * (3 + 2));  // VMEM instructions per super-body
+};
+struct CascInvBands {
+    const float *A2, *H2, *V2, *D2, *H1, *V1, *D1;
+};
+
+template <int HLEN>
+__global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __restrict__ out, int Nr, int Nc, int VL,
+                                                     float* __restrict__ trash, CascMap cm, Taps2<float> f)
+{
+    using G = CascInvGeom<HLEN>;
+    constexpr int H2 = G::H2, C = G::C, SHIFT = G::SHIFT, NB1 = G::NB1, NB2 = G::NB2, NBT = G::NBT, WIN1 = G::WIN1, WIN2 = G::WIN2;
+    static_assert(G::VM_SB - 3 <= 63, "vmcnt is a 6-bit counter");
+    const int lane = threadIdx.x & 63;
+    const int xcd = blockIdx.x & 7;
+    const int wi = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    if (wi >= cm.cpx * cm.strips) return;
+    const int cy = xcd * cm.cpx + wi / cm.strips;
+    const int strip = wi % cm.strips;
+    const int Nr1 = Nr >> 1, Nc1 = Nc >> 1, Nr2 = Nr >> 2, Nc2 = Nc >> 2;
+    const int nchunks = 8 * cm.cpx;
+    // level-l coefficient rows [ya, ye) of the chunk (mod Nr1): even heights, common start parity BASE
+    const int ya = G::BASE + 2 * (int)(((long long)cy * (Nr1 >> 1)) / nchunks);
+    const int ye = G::BASE + 2 * (int)(((long long)(cy + 1) * (Nr1 >> 1)) / nchunks);
+    const int rows1 = ye - ya;
+    if (rows1 <= 0) return;
+    const int cx1 = strip * VL * 2 + 2 * (lane - NBT);  // first of the lane's two level-l coefficient columns
+    const bool valid = (lane >= NBT) && (lane < NBT + VL) && (cx1 < Nc1);
+    const int cx1w = wrapi(cx1, Nc1);
+    const int cx2w = cx1w >> 1;
+    const int gA = ya - C;              // A_l row of stream index r1 = 0
+    const int P0 = (gA + SHIFT) >> 1;   // level-(l+1) window position of step 0 (exact division: see BASE)
+    const int r2base = P0 - C;          // level-(l+1) coefficient row of r2 = 0
+    const int nrows1 = rows1 + H2 - 1 + SHIFT;
+    const int nsteps = (nrows1 + 1) >> 1;
+
+    const float* const pA2 = b.A2 + cx2w;
+    const float* const pH2 = b.H2 + cx2w;
+    const float* const pV2 = b.V2 + cx2w;
+    const float* const pD2 = b.D2 + cx2w;
+    const float* const pH1 = b.H1 + cx1w;
+    const float* const pV1 = b.V1 + cx1w;
+    const float* const pD1 = b.D1 + cx1w;
+    auto off2 = [&](int r2) { return (size_t)wrap1(r2base + r2, Nr2) * Nc2; };
+    auto off1 = [&](int r1) { return (size_t)wrap1(gA + r1, Nr1) * Nc1; };
+
+    v2f r2av[H2], r2hd[H2];               // level l+1 ring: (A,V) and (H,D) of the lane's column
+    v2f ra[H2], rh[H2], rv[H2], rd[H2];   // level l ring: the lane's two columns of each band
+#pragma unroll
+    for (int k = 0; k < H2; k++) ra[k] = rh[k] = rv[k] = rd[k] = v2f{0.f, 0.f};
+    float q2[H2][4];                      // row registers in flight, level l+1 (one per step of a super-body)
+    v2f q1[HLEN][3];                      // row registers in flight, level l (two per step)
+    {
+#pragma unroll
+        for (int r = 0; r < H2 - 1; r++) {
+            const size_t o = off2(r);
+            r2av[r] = v2f{pA2[o], pV2[o]};
+            r2hd[r] = v2f{pH2[o], pD2[o]};
+        }
+        r2av[H2 - 1] = r2hd[H2 - 1] = v2f{0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < H2; p++) {
+            const size_t o = off2(H2 - 1 + p);
+            q2[p][0] = pA2[o];
+            q2[p][1] = pH2[o];
+            q2[p][2] = pV2[o];
+            q2[p][3] = pD2[o];
+        }
+#pragma unroll
+        for (int q = 0; q < HLEN; q++) {
+            const size_t o = off1(q);
+            q1[q][0] = *reinterpret_cast<const v2f*>(pH1 + o);
+            q1[q][1] = *reinterpret_cast<const v2f*>(pV1 + o);
+            q1[q][2] = *reinterpret_cast<const v2f*>(pD1 + o);
+        }
+    }
+
+    float* const tr = trash + (size_t)(blockIdx.x & 255) * 1024 + (threadIdx.x >> 6) * 256 + lane * 4;
+    float* const obase = out + 2 * (size_t)(valid ? cx1 : 0);
+
+    // one output row of level l from the ring window starting at slot S0 with tap parity OFF (cf. k_inv2d_stream::emit)
+    auto emit = [&](auto S0, auto OFF, int g) {
+        constexpr int s0 = decltype(S0)::value, off = decltype(OFF)::value;
+        v2f sa = {0.f, 0.f}, sh = {0.f, 0.f}, sv = {0.f, 0.f}, sd = {0.f, 0.f};
+        static_for<H2>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int s = (s0 + j) % H2;
+            constexpr int k = HLEN - 1 - (2 * j + off);
+            const v2f fl = splat(f.a[k]), fh = splat(f.b[k]);
+            sa = pk_fma(ra[s], fl, sa);
+            sh = pk_fma(rh[s], fh, sh);
+            sv = pk_fma(rv[s], fl, sv);
+            sd = pk_fma(rd[s], fh, sd);
+        });
+        const v2f t1o = sa + sh, t2o = sv + sd;
+        float t1[WIN1], t2[WIN1];
+        t1[NB1 * 2] = t1o.x;
+        t1[NB1 * 2 + 1] = t1o.y;
+        t2[NB1 * 2] = t2o.x;
+        t2[NB1 * 2 + 1] = t2o.y;
+#pragma unroll
+        for (int k = 0; k < NB1; k++) {
+            const int dl = (NB1 - 1 - k) * 2, sl = (NB1 - k) * 2, dr = (NB1 + 1 + k) * 2, sr = (NB1 + k) * 2;
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) {
+                t1[dl + cc] = dpp_shr1(t1[sl + cc]);
+                t2[dl + cc] = dpp_shr1(t2[sl + cc]);
+                t1[dr + cc] = dpp_shl1(t1[sr + cc]);
+                t2[dr + cc] = dpp_shl1(t2[sr + cc]);
+            }
+        }
+        float o4[4];
+        auto pair_out = [&](auto E0) {
+            constexpr int e0 = decltype(E0)::value;
+            constexpr int pl = (e0 + SHIFT) >> 1;
+            v2f s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < H2; j++) {
+                const int m = HLEN - 1 - 2 * j;
+                s1 = pk_fma(splat(t1[NB1 * 2 + pl - C + j]), v2f{f.a[m - 1], f.a[m]}, s1);
+                s2 = pk_fma(splat(t2[NB1 * 2 + pl - C + j]), v2f{f.b[m - 1], f.b[m]}, s2);
+            }
+            const v2f o = s1 + s2;
+            o4[e0] = o.x;
+            o4[e0 + 1] = o.y;
+        };
+        auto single_out = [&](auto E) {
+            constexpr int eo = decltype(E)::value;
+            constexpr int gp = eo + SHIFT;
+            constexpr int pl = gp >> 1, offx = 1 - (gp & 1);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < H2; j++) {
+                const int k = HLEN - 1 - (2 * j + offx);
+                s1 = __builtin_fmaf(t1[NB1 * 2 + pl - C + j], f.a[k], s1);
+                s2 = __builtin_fmaf(t2[NB1 * 2 + pl - C + j], f.b[k], s2);
+            }
+            o4[eo] = s1 + s2;
+        };
+        if constexpr (SHIFT == 0) {
+            pair_out(std::integral_constant<int, 0>{});
+            pair_out(std::integral_constant<int, 2>{});
+        } else {
+            single_out(std::integral_constant<int, 0>{});
+            pair_out(std::integral_constant<int, 1>{});
+            single_out(std::integral_constant<int, 3>{});
+        }
+        const bool st = valid && (g >= 0) && (g < 2 * rows1);
+        asm_store(st ? obase + (size_t)wrap1(2 * ya + g, Nr) * Nc : tr, v4f{o4[0], o4[1], o4[2], o4[3]});
+    };
+
+    // one row of A_l (the lane's two columns) from the level-(l+1) ring window starting at slot S0, tap parity OFF
+    auto synth2 = [&](auto S0, auto OFF, float& a0, float& a1) {
+        constexpr int s0 = decltype(S0)::value, off = decltype(OFF)::value;
+        v2f sav = {0.f, 0.f}, shd = {0.f, 0.f};
+        static_for<H2>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int s = (s0 + j) % H2;
+            constexpr int k = HLEN - 1 - (2 * j + off);
+            sav = pk_fma(r2av[s], splat(f.a[k]), sav);
+            shd = pk_fma(r2hd[s], splat(f.b[k]), shd);
+        });
+        const v2f t = sav + shd;  // (t1, t2) of the lane's column
+        float t1[WIN2], t2[WIN2];
+        t1[NB2] = t.x;
+        t2[NB2] = t.y;
+#pragma unroll
+        for (int k = 0; k < NB2; k++) {
+            t1[NB2 - 1 - k] = dpp_shr1(t1[NB2 - k]);
+            t2[NB2 - 1 - k] = dpp_shr1(t2[NB2 - k]);
+            t1[NB2 + 1 + k] = dpp_shl1(t1[NB2 + k]);
+            t2[NB2 + 1 + k] = dpp_shl1(t2[NB2 + k]);
+        }
+        float o2[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int gp = e + SHIFT;
+            const int pl = gp >> 1, offx = 1 - (gp & 1);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < H2; j++) {
+                const int k = HLEN - 1 - (2 * j + offx);
+                s1 = __builtin_fmaf(t1[NB2 + pl - C + j], f.a[k], s1);
+                s2 = __builtin_fmaf(t2[NB2 + pl - C + j], f.b[k], s2);
+            }
+            o2[e] = s1 + s2;
+        }
+        a0 = o2[0];
+        a1 = o2[1];
+    };
+
+    constexpr int kWait2 = G::VM_SB - 4, kWait1 = G::VM_SB - 3;
+    auto step = [&](auto Pp, int sb) {
+        constexpr int p = decltype(Pp)::value;
+        const int s = sb * H2 + p;
+        // ---- level l+1: coefficient row r2 = H2-1+s completes the window of step s ----
+        asm_wait4<kWait2>(q2[p][0], q2[p][1], q2[p][2], q2[p][3]);
+        r2av[(H2 - 1 + p) % H2] = v2f{q2[p][0], q2[p][2]};
+        r2hd[(H2 - 1 + p) % H2] = v2f{q2[p][1], q2[p][3]};
+        {
+            const size_t o = off2(2 * H2 - 1 + s);  // the row this step needs one super-body ahead
+            asm_load(q2[p][0], pA2 + o);
+            asm_load(q2[p][1], pH2 + o);
+            asm_load(q2[p][2], pV2 + o);
+            asm_load(q2[p][3], pD2 + o);
+        }
+        static_for<2>([&](auto I) {
+            constexpr int idx = decltype(I)::value;  // 0: tap parity 1 (A_l row 2P-SHIFT), 1: parity 0 (the next row)
+            constexpr int q = 2 * p + idx;           // position of the A_l row in the super-body
+            float a0, a1;
+            synth2(std::integral_constant<int, p % H2>{}, std::integral_constant<int, 1 - idx>{}, a0, a1);
+            // ---- level l: stream row r1 enters the ring with its H,V,D row ----
+            const int r1 = 2 * s + idx;
+            asm_wait3<kWait1>(q1[q][0], q1[q][1], q1[q][2]);
+            ra[q % H2] = v2f{a0, a1};
+            rh[q % H2] = q1[q][0];
+            rv[q % H2] = q1[q][1];
+            rd[q % H2] = q1[q][2];
+            {
+                const size_t o = off1(r1 + HLEN);
+                asm_load(q1[q][0], pH1 + o);
+                asm_load(q1[q][1], pV1 + o);
+                asm_load(q1[q][2], pD1 + o);
+            }
+            const int g1 = 2 * (r1 - (H2 - 1)) - SHIFT;
+            emit(std::integral_constant<int, (q + 1) % H2>{}, std::integral_constant<int, 1>{}, g1);
+            emit(std::integral_constant<int, (q + 1) % H2>{}, std::integral_constant<int, 0>{}, g1 + 1);
+        });
+    };
+
+    static_for<H2>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        asm_drain1(q2[k][0]);
+        asm_drain1(q2[k][1]);
+        asm_drain1(q2[k][2]);
+        asm_drain1(q2[k][3]);
+    });
+    static_for<HLEN>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        asm_drain1(q1[k][0]);
+        asm_drain1(q1[k][1]);
+        asm_drain1(q1[k][2]);
+    });
+    for (int sb = 0;; sb++) {
+        bool fin = false;
+        static_for<H2>([&](auto Pp) {
+            if (!fin) {
+                step(Pp, sb);
+                fin = (sb * H2 + decltype(Pp)::value + 1 >= nsteps);
+            }
+        });
+        if (fin) break;
+    }
+    static_for<H2>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        asm_drain1(q2[k][0]);
+        asm_drain1(q2[k][1]);
+        asm_drain1(q2[k][2]);
+        asm_drain1(q2[k][3]);
+    });
+    static_for<HLEN>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        asm_drain1(q1[k][0]);
+        asm_drain1(q1[k][1]);
+        asm_drain1(q1[k][2]);
+    });
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+#define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
+
+static int g_casc_enable = -1;
+static bool casc_enabled()
+{
+    if (g_casc_enable < 0) g_casc_enable = env_int("PDWT_CASC", 1);
+    return g_casc_enable == 1;
+}
+void casc_set_enabled(int on) { g_casc_enable = on ? 1 : 0; }
+
+template <int HLEN>
+static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, int nr, int nc, const Taps2<float>& f2)
+{
+    TapsLH f;
+    for (int k = 0; k < PDWT_MAX_FILTER_WIDTH; k++) f.t[k] = v2f{f2.a[k], f2.b[k]};
+    constexpr int MAXVL = CascGeom<HLEN>::MAXVL;
+    const int strips = idiv_up(nc, MAXVL * 4);
+    const int VL = idiv_up(nc / 4, strips);
+    // chunk rows: a multiple of 8 (one band per XCD), ~PDWT_CASC_WAVES waves in total, at least 4 level-2 rows each.
+    // One wave per SIMD (1024) is the optimum: every extra chunk row recomputes 3(hlen-2) input rows of halo
+    // (measured 27.2 us @1024, 30.9 @2048, 35 @4096 for 4096^2 db4).
+    int cpx = env_int("PDWT_CASC_WAVES", 1024) / (8 * strips);
+    if (cpx > nr / 4 / 4 / 8) cpx = nr / 4 / 4 / 8;
+    if (cpx < 1) cpx = 1;
+    const CascMap cm = {cpx, strips};
+    const dim3 grid((unsigned)(8 * idiv_up(cpx * strips, 4)));
+    KTimer kt(K_FWD2D_CASC);
+    // (PF = 2 measured no faster on MI355X: 28.5 vs 27.2 us at 4096^2 db4 -- the kernel is not latency-bound)
+    hipLaunchKernelGGL((k_fwd2d_casc<HLEN, 1>), grid, dim3(256), 0, stream(), in, b, nr, nc, VL, trash, cm, f);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
+#define PDWT_CASC_FWD_HLENS(X) X(4) X(6) X(8) X(10)
+
+int fwd2d_casc_f32(const float* in, float* H1, float* V1, float* D1, float* A2, float* H2, float* V2, float* D2, float* trash, int nr,
+                   int nc, int hlen, const Taps2<float>& f)
+{
+    if (!casc_enabled() || !stream_enabled() || !trash) return 1;
+    if ((nr & 3) || (nc & 3) || nc < 256 || nr < 16 * hlen) return 1;
+    if ((long long)nr * nc < (long long)env_int("PDWT_CASC_MIN", 1024 * 1024)) return 1;
+    if (!al16(in) || !al16(H1) || !al16(V1) || !al16(D1) || !al16(A2) || !al16(H2) || !al16(V2) || !al16(D2)) return 1;
+    const CascBands b = {H1, V1, D1, A2, H2, V2, D2};
+    switch (hlen) {
+#define X(H) \
+    case H: return launch_fwd_casc<H>(in, b, trash, nr, nc, f);
+        PDWT_CASC_FWD_HLENS(X)
+#undef X
+        default: return 1;
+    }
+}
+
+template <int HLEN>
+static int launch_inv_casc(const CascInvBands& b, float* out, float* trash, int nr, int nc, const Taps2<float>& f)
+{
+    constexpr int MAXVL = CascInvGeom<HLEN>::MAXVL;
+    const int nc1 = nc / 2;
+    const int strips = idiv_up(nc1, MAXVL * 2);
+    const int VL = idiv_up(nc1 / 2, strips);
+    int cpx = env_int("PDWT_CASC_IWAVES", 1024) / (8 * strips);
+    if (cpx > nr / 2 / 8 / 8) cpx = nr / 2 / 8 / 8;  // at least 8 level-l coefficient rows per chunk
+    if (cpx < 1) cpx = 1;
+    const CascMap cm = {cpx, strips};
+    const dim3 grid((unsigned)(8 * idiv_up(cpx * strips, 4)));
+    KTimer kt(K_INV2D_CASC);
+    hipLaunchKernelGGL(k_inv2d_casc<HLEN>, grid, dim3(256), 0, stream(), b, out, nr, nc, VL, trash, cm, f);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
+#define PDWT_CASC_INV_HLENS(X) X(4) X(6) X(8)
+
+int inv2d_casc_f32(const float* A2, const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1,
+                   float* out, float* trash, int nr, int nc, int hlen, const Taps2<float>& f)
+{
+    if (!casc_enabled() || !stream_enabled() || !trash) return 1;
+    if ((nr & 3) || (nc & 3) || nc < 256 || nr < 32 * hlen) return 1;
+    if ((long long)nr * nc < (long long)env_int("PDWT_CASC_MIN", 1024 * 1024)) return 1;
+    if (!al16(out) || !al16(H1) || !al16(V1) || !al16(D1) || !al16(A2) || !al16(H2) || !al16(V2) || !al16(D2) || !al16(trash)) return 1;
+    const CascInvBands b = {A2, H2, V2, D2, H1, V1, D1};
+    switch (hlen) {
+#define X(H) \
+    case H: return launch_inv_casc<H>(b, out, trash, nr, nc, f);
+        PDWT_CASC_INV_HLENS(X)
+#undef X
+        default: return 1;
+    }
+}
+
+}  // namespace pdwt

@@ -22,62 +22,10 @@
 // Arithmetic (tap order, one FMA per tap, pass order) is identical to the tiled kernels in dwt.hip
 // and to the CPU oracle, so the outputs are bit-identical to both (tests/test_gpu_parity.py).
 // Reference code replaced: w_kern_forward_pass1/2, w_kern_inverse_pass1/2 (src/separable.cu:91-328).
-#include <stdlib.h>
-
-#include <type_traits>
-
-#include "common.hpp"
 #include "dwt_stream.hpp"
+#include "stream_dev.hpp"
 
 namespace pdwt {
-
-// bound_ctrl:1 + no `old` operand: the lane without a source reads 0 and the compiler needs no
-// initialising v_mov per shift (that lane is a halo lane and produces no output anyway)
-__device__ __forceinline__ float dpp_shr1(float src)
-{  // lane i <- lane i-1
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float dpp_shl1(float src)
-{  // lane i <- lane i+1
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), 0x130, 0xf, 0xf, true));
-}
-
-__device__ __forceinline__ int wrapi(int s, int n)
-{
-    s %= n;
-    return s < 0 ? s + n : s;
-}
-// single conditional wrap: valid for -n <= s < 2n (row indices of a chunk; the dispatcher guarantees n >= 2*hlen)
-__device__ __forceinline__ int wrap1(int s, int n) { return s < 0 ? s + n : (s >= n ? s - n : s); }
-
-// compile-time loop: ring slots must be constants for the rings to stay in registers
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for_impl(F&& fn)
-{
-    if constexpr (I < N) {
-        fn(std::integral_constant<int, I>{});
-        static_for_impl<I + 1, N>(fn);
-    }
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& fn)
-{
-    static_for_impl<0, N>(fn);
-}
-
-// Packed-f32 arithmetic.  gfx950 issues v_pk_fma_f32 (2 FMAs per lane) in the slot of one VALU op and can
-// broadcast either half of a 64-bit operand (op_sel), so the kernels are written on explicit float pairs:
-//   forward : (lo,hi) += x * (L[k],H[k])   -- one input sample feeds both filters; taps travel as pairs
-//   inverse : (c0,c1) += (band[c0],band[c1]) * tap   -- the two coefficient columns a lane owns
-// Each scalar still accumulates its taps in the reference order with one FMA per tap (bit-exact vs the oracle).
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f splat(float x) { return v2f{x, x}; }
-
-// forward taps as (L[k], H[k]) pairs, by value in the kernarg segment (-> SGPR pairs)
-struct TapsLH {
-    v2f t[PDWT_MAX_FILTER_WIDTH];
-};
 
 // =================================================================================================
 // forward
@@ -90,52 +38,6 @@ struct FwdGeom {
     static constexpr int WIN = NIN * (2 * NB + 1);               // window registers
     static constexpr int MAXVL = 64 - 2 * NB;                    // lanes that produce output
 };
-
-// Block -> (chunk row, strip group) map.  Workgroups are dispatched round-robin over the 8 XCDs
-// (block b -> XCD b % 8), each with a private L2.  Vertically adjacent chunks share hlen-2 halo rows, so
-// every XCD gets a contiguous band of chunk rows and walks it top to bottom: the halo rows are then L2
-// hits instead of a second trip to Infinity Cache / HBM.  Pure speed: any other placement is still correct.
-struct ChunkMap {
-    int gx;       // workgroups per chunk row
-    int nchunks;  // chunk rows
-    int rpx;      // chunk rows per XCD band = ceil(nchunks / 8)
-};
-__device__ __forceinline__ bool chunk_of_block(const ChunkMap& m, int& cy, int& bx)
-{
-    const int b = blockIdx.x;
-    const int xcd = b & 7, slot = b >> 3;
-    cy = xcd * m.rpx + slot / m.gx;
-    bx = slot % m.gx;
-    return cy < min(m.nchunks, (xcd + 1) * m.rpx);
-}
-
-typedef float v4f __attribute__((ext_vector_type(4)));
-template <int N> struct VecOf;
-template <> struct VecOf<4> { using type = v4f; };
-template <> struct VecOf<2> { using type = v2f; };
-__device__ __forceinline__ void vstore(float* p, const float (&a)[2]) { *reinterpret_cast<float2*>(p) = make_float2(a[0], a[1]); }
-__device__ __forceinline__ void vstore(float* p, const float (&a)[1]) { *p = a[0]; }
-
-// ---- hand-counted memory pipeline (steady-state loop only) -----------------------------------------
-// hipcc sizes every s_waitcnt for the worst incoming edge and, on gfx9, counts stores in vmcnt too, so a
-// compiler-scheduled loop ends every body with vmcnt(0): the wave drains its stores and its prefetched loads
-// before it may compute again.  In the branch-free steady-state bodies all global loads and stores are
-// therefore inline asm (invisible to hipcc's counting) and each consumer waits with an exact
-// `s_waitcnt vmcnt(N)`, N = number of VMEM instructions the wave issues between that load and its use.
-// Memory instructions retire in issue order, so "at most N outstanding" means the load has landed while the
-// N younger loads/stores stay in flight.  Rules that keep the count exact: every lane-predicated store goes
-// to a trash slot instead of being branched around; the loop is entered and left through vmcnt(0).
-__device__ __forceinline__ void asm_load(v4f& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
-__device__ __forceinline__ void asm_load(v2f& d, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
-__device__ __forceinline__ void asm_store(float* p, v2f d) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(d) : "memory"); }
-__device__ __forceinline__ void asm_store(float* p, float d) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(d) : "memory"); }
-__device__ __forceinline__ void asm_store(float* p, v4f d) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(d) : "memory"); }
-template <int N, typename V>
-__device__ __forceinline__ void asm_wait2(V& a, V& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
-template <int N, typename V>
-__device__ __forceinline__ void asm_wait4(V& a, V& b, V& c, V& d) { asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory"); }
-template <typename V>
-__device__ __forceinline__ void asm_drain1(V& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) : : "memory"); }
 
 template <int HLEN, int NIN>
 __global__ __launch_bounds__(256) void k_fwd2d_stream(const float* __restrict__ in, float* __restrict__ cA, float* __restrict__ cH,
@@ -489,12 +391,6 @@ __global__ __launch_bounds__(256) void k_inv2d_stream(const float* __restrict__ 
 // =================================================================================================
 // host dispatch
 // =================================================================================================
-static int env_int(const char* name, int dflt)
-{
-    const char* e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
-}
-
 static int g_stream_enable = -1;
 bool stream_enabled()
 {
@@ -516,16 +412,6 @@ static int pick_rows(int nrows_total, int strips, int unit)
     }
     (void)unit;
     return R;
-}
-
-static ChunkMap make_map(int gx, int nchunks, dim3* grid)
-{
-    ChunkMap m;
-    m.gx = gx;
-    m.nchunks = nchunks;
-    m.rpx = idiv_up(nchunks, 8);
-    *grid = dim3((unsigned)(8 * m.rpx * gx));
-    return m;
 }
 
 #define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
@@ -570,8 +456,6 @@ static int launch_inv(const float* cA, const float* cH, const float* cV, const f
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
-
-static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // filter lengths with a streaming instantiation (register budget: one unrolled body holds HLEN rows in flight)
 #define PDWT_STREAM_FWD_HLENS(X) X(4) X(6) X(8) X(10)

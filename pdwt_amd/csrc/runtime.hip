@@ -40,6 +40,7 @@ static const char* const g_knames[K_COUNT] = {
     "fwd2d_fused", "inv2d_fused", "ana_rows", "ana_cols", "syn_cols", "syn_rows",
     "swt_ana_rows", "swt_ana_cols", "swt_syn_cols", "swt_syn_rows",
     "haar2d_fwd", "haar2d_inv", "haar1d_fwd", "haar1d_inv", "soft_thresh", "abs_sum", "abs_sum_final",
+    "fwd2d_casc", "inv2d_casc",
 };
 struct KRec { int id; hipEvent_t e0, e1; };
 static thread_local bool g_kt_on = false;

@@ -363,3 +363,32 @@ def test_fused_small_levels_equal_per_level(wname):
         for a, b in zip(res[0][0], res[1][0]):
             assert np.array_equal(a, b)
         assert np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("wname", ["db2", "db3", "db4", "db5"])
+def test_cascade_equals_per_level(wname, monkeypatch):
+    """dwt_casc.hip (two levels per launch, approximation kept in registers) is the same arithmetic as one launch per level,
+    and both match the oracle."""
+    monkeypatch.setenv("PDWT_CASC_MIN", "0")
+    rs = np.random.RandomState(29)
+    L = pdwt_amd.hip()
+    for shape, levels in (((512, 512), 2), ((512, 768), 3), ((1024, 512), 4), ((256, 1280), 2), ((1096, 520), 3)):
+        x = rs.uniform(0, 255, shape).astype(np.float32)
+        res = []
+        for casc in (1, 0):
+            assert L.pdwt_debug_set(b"casc", casc) == 0
+            try:
+                W = pdwt_amd.Wavelets(x, wname, levels)
+                W.forward()
+                c = W.coeffs
+                W.inverse()
+                res.append((c, W.get_image()))
+            finally:
+                L.pdwt_debug_set(b"casc", 1)
+        for a, b in zip(res[0][0], res[1][0]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(res[0][1], res[1][1])
+        O = orc.OracleWavelets(x, wname, levels)
+        O.forward()
+        for a, b in zip(res[0][0], O.coeffs):
+            assert band_err(a, b) <= TOL[np.dtype(np.float32)]
