@@ -562,12 +562,13 @@ static int launch_syn_cols(const T* cA, const T* cH, const T* cV, const T* cD, T
 
 // one 2D forward level: in (nr x nc) -> A,H,V,D (nr2 x nc2); t1/t2 scratch for the two-pass form
 template <typename T>
-static int level_fwd2d(const T* in, T* cA, T* cH, T* cV, T* cD, T* t1, T* t2, int nr, int nc, int hlen, const Taps2<T>& f)
+static int level_fwd2d(const T* in, T* cA, T* cH, T* cV, T* cD, T* t1, T* t2, bool t1_is_trash, int nr, int nc, int hlen, const Taps2<T>& f)
 {
     if constexpr (sizeof(T) == 4) {  // float32 fast path: LDS-free streaming kernel (dwt_stream.hip)
         if (!force_twopass()) {
-            // t1 (the two-pass scratch) is unused on this path: it serves as the trash area of the streaming kernels
-            float* trash = ((size_t)nr * div2(nc) >= kStreamTrashFloats) ? (float*)t1 : nullptr;
+            // t1 (the two-pass scratch, sized for the FULL image) is unused on this path: it serves as the trash area of
+            // the streaming kernels whenever it is big enough
+            float* trash = t1_is_trash ? (float*)t1 : nullptr;
             const int rc = fwd2d_stream_f32(in, cA, cH, cV, cD, trash, nr, nc, hlen, f);
             if (rc <= 0) return rc;
         }
@@ -628,8 +629,10 @@ static int level_inv2d(const T* cA, const T* cH, const T* cV, const T* cD, T* ou
 template <typename T>
 struct Scratch {
     T *t1, *t2, *ping[2];
+    bool t1_is_trash;  // t1 holds >= kStreamTrashFloats floats (and 16 rows of the image): usable as the streaming kernels' trash area
     Scratch(T* tmp, int Nr, int Nc, int ndims)
     {
+        t1_is_trash = (ndims == 2) && ((size_t)Nr * div2(Nc) * sizeof(T) >= kStreamTrashFloats * sizeof(float)) && Nr >= 32;
         auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
         const size_t half = up((size_t)Nr * div2(Nc));
         const size_t quarter = up((size_t)(ndims == 2 ? div2(Nr) : Nr) * div2(Nc));
@@ -676,7 +679,7 @@ static int forward_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typ
             // two levels in one launch, the approximation between them stays in registers (dwt_casc.hip)
             if (lev + 1 < w.nlevels && !force_twopass()) {
                 T* a2 = (lev + 2 == w.nlevels) ? c[0] : s.ping[pp];
-                float* trash = ((size_t)nr * div2(nc) >= kStreamTrashFloats) ? (float*)s.t1 : nullptr;
+                float* trash = s.t1_is_trash ? (float*)s.t1 : nullptr;
                 rc = fwd2d_casc_f32(in, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], a2, c[3 * lev + 4], c[3 * lev + 5], c[3 * lev + 6],
                                     trash, nr, nc, w.hlen, f);
                 if (rc < 0) return rc;
@@ -691,7 +694,7 @@ static int forward_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typ
             }
         }
         T* aout = (lev == w.nlevels - 1) ? c[0] : s.ping[pp];
-        rc = level_fwd2d(in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], s.t1, s.t2, nr, nc, w.hlen, f);
+        rc = level_fwd2d(in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], s.t1, s.t2, s.t1_is_trash, nr, nc, w.hlen, f);
         if (rc != PDWT_OK) return rc;
         in = aout;
         pp ^= 1;
@@ -743,7 +746,7 @@ static int inverse_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typ
             // pairs are (1,0), (3,2), ... so that the finest -- most expensive -- level is always in a pair
             if ((i & 1) && !force_twopass()) {
                 T* out = (i == 1) ? d_image : s.ping[pp];
-                float* trash = ((size_t)tNr[i - 1] * tNc[i] >= kStreamTrashFloats) ? (float*)s.t1 : nullptr;
+                float* trash = s.t1_is_trash ? (float*)s.t1 : nullptr;
                 rc = inv2d_casc_f32(a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], c[3 * i - 2], c[3 * i - 1], c[3 * i], out, trash, tNr[i - 1],
                                     tNc[i - 1], w.hlen, f);
                 if (rc < 0) return rc;

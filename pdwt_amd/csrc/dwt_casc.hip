@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in
     // [x*cpx, (x+1)*cpx) and its waves walk that band strip by strip, so neighbours in space are neighbours in time
     const int lane = threadIdx.x & 63;
     const int xcd = blockIdx.x & 7;
-    const int wi = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    // the wave index is uniform, but only readfirstlane tells the compiler: everything derived from it (rows, row
+    // bases, trip counts, predicates) then lives on the scalar unit
+    const int wi = (blockIdx.x >> 3) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wi >= cm.cpx * cm.strips) return;
     const int cy = xcd * cm.cpx + wi / cm.strips;
     const int strip = wi % cm.strips;
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in
     const int xo = wrapi(x, Nc);
     const int yb = 4 * j0 - 3 * C;           // input row of chunk-local row 0 (A1 row n <-> input rows 2n .. 2n+HLEN-1)
     const int NA1 = 2 * rows2 + HLEN - 2;    // A1 rows the chunk computes; n in [C, C+2*rows2) are its own
+    const int rlast = 2 * NA1 + HLEN - 3;    // last input row the chunk needs
 
     v2f ring[HLEN][2];  // level 1: (lo,hi) row-pass results of the last HLEN input rows, 2 columns
     v2f ring2[HLEN];    // level 2: (lo,hi) row-pass results of the last HLEN A1 rows, 1 column
@@ -90,6 +93,9 @@ __global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in
 
     const float* const lbase = in + xo;
     auto rowptr = [&](int r) { return lbase + (size_t)wrap1(yb + r, Nr) * Nc; };
+    // steady state: uniform row base on the scalar unit + loop-invariant per-lane byte offset (stream_dev.hpp)
+    auto rowbase = [&](int r) { return in + (size_t)wrap1(yb + r, Nr) * Nc; };
+    const unsigned xoff = (unsigned)xo * 4u;
 
     auto row_pass1 = [&](const v4f& v, v2f (&lh)[2]) {
         float w[WIN1];
@@ -148,8 +154,9 @@ __global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in
         });
     }
 
-    float* const tr = trash + (size_t)(blockIdx.x & 255) * 1024 + (threadIdx.x >> 6) * 256 + lane * 2;
-    const size_t ocol1 = (size_t)(x >> 1), ocol2 = (size_t)(x >> 2);
+    float* const tr = trash + (size_t)(blockIdx.x & 15) * Nc2;  // a trash ROW (the dispatcher checks the area holds 16 of them)
+    const unsigned off1 = (unsigned)(valid ? x >> 1 : 0) * 4u, off2 = (unsigned)(valid ? x >> 2 : 0) * 4u;
+    const lanemask_t vmask = __ballot(valid);
     static_for<NV>([&](auto K) { asm_drain1(v[decltype(K)::value]); });
     auto a1_row = [&](auto A, int sb) {
             constexpr int a = decltype(A)::value;  // A1 row within the super-body
@@ -162,8 +169,9 @@ __global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in
             row_pass1(v[r0], ring[s0]);
             row_pass1(v[r1], ring[s1]);
             const int rn = 2 * n + HLEN - 2 + NV;  // the rows these registers hold DIST A1 rows ahead
-            asm_load(v[r0], rowptr(rn));
-            asm_load(v[r1], rowptr(rn + 1));
+            // (clamped to the chunk's last row: the prefetch past the end re-reads a cached line instead of fetching new ones)
+            asm_load_s(v[r0], rowbase(min(rn, rlast)), xoff);
+            asm_load_s(v[r1], rowbase(min(rn + 1, rlast)), xoff);
             // level-1 column pass
             v2f ah[2], vd[2];
 #pragma unroll
@@ -179,11 +187,12 @@ __global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in
                 }
             });
             {
-                const bool st = valid && (n >= C) && (n < C + 2 * rows2);
-                const size_t o = (size_t)(2 * j0 + n - C) * Nc2 + ocol1;
-                asm_store(st ? b.H1 + o : tr, v2f{ah[0].y, ah[1].y});
-                asm_store(st ? b.V1 + o : tr + 128, v2f{vd[0].x, vd[1].x});
-                asm_store(st ? b.D1 + o : tr, v2f{vd[0].y, vd[1].y});
+                // rows outside the chunk's own range go to the trash rows (uniform select on the scalar unit)
+                const bool own = (n >= C) && (n < C + 2 * rows2);
+                const size_t o = (size_t)(2 * j0 + n - C) * Nc2;
+                asm_store_sm(own ? b.H1 + o : tr, off1, v2f{ah[0].y, ah[1].y}, vmask);
+                asm_store_sm(own ? b.V1 + o : tr, off1, v2f{vd[0].x, vd[1].x}, vmask);
+                asm_store_sm(own ? b.D1 + o : tr, off1, v2f{vd[0].y, vd[1].y}, vmask);
             }
             // level-2 row pass on the A1 pair; ring2 slot = n % HLEN = a
             row_pass2(ah[0].x, ah[1].x, ring2[a]);
@@ -198,12 +207,12 @@ __global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in
                     vd2 = pk_fma(splat(ring2[s].y), t, vd2);
                 });
                 const int jl = (n - (HLEN - 1)) >> 1;
-                const bool st = valid && (n >= HLEN - 1) && (jl < rows2);
-                const size_t o = (size_t)(j0 + jl) * Nc4 + ocol2;
-                asm_store(st ? b.A2 + o : tr, ah2.x);
-                asm_store(st ? b.H2 + o : tr + 128, ah2.y);
-                asm_store(st ? b.V2 + o : tr + 1, vd2.x);
-                asm_store(st ? b.D2 + o : tr + 129, vd2.y);
+                const bool own = (n >= HLEN - 1) && (jl < rows2);
+                const size_t o = (size_t)(j0 + jl) * Nc4;
+                asm_store_sm(own ? b.A2 + o : tr, off2, ah2.x, vmask);
+                asm_store_sm(own ? b.H2 + o : tr, off2, ah2.y, vmask);
+                asm_store_sm(own ? b.V2 + o : tr, off2, vd2.x, vmask);
+                asm_store_sm(own ? b.D2 + o : tr, off2, vd2.y, vmask);
             }
     };
     for (int sb = 0;; sb++) {
@@ -257,7 +266,9 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
     static_assert(G::VM_SB - 3 <= 63, "vmcnt is a 6-bit counter");
     const int lane = threadIdx.x & 63;
     const int xcd = blockIdx.x & 7;
-    const int wi = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    // the wave index is uniform, but only readfirstlane tells the compiler: everything derived from it (rows, row
+    // bases, trip counts, predicates) then lives on the scalar unit
+    const int wi = (blockIdx.x >> 3) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wi >= cm.cpx * cm.strips) return;
     const int cy = xcd * cm.cpx + wi / cm.strips;
     const int strip = wi % cm.strips;
@@ -287,6 +298,9 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
     const float* const pD1 = b.D1 + cx1w;
     auto off2 = [&](int r2) { return (size_t)wrap1(r2base + r2, Nr2) * Nc2; };
     auto off1 = [&](int r1) { return (size_t)wrap1(gA + r1, Nr1) * Nc1; };
+    // steady state: uniform row bases (scalar unit) + loop-invariant per-lane byte offsets (stream_dev.hpp)
+    const unsigned voff2 = (unsigned)cx2w * 4u, voff1 = (unsigned)cx1w * 4u, voffo = (unsigned)(valid ? cx1 : 0) * 8u;
+    const lanemask_t vmask = __ballot(valid);
 
     v2f r2av[H2], r2hd[H2];               // level l+1 ring: (A,V) and (H,D) of the lane's column
     v2f ra[H2], rh[H2], rv[H2], rd[H2];   // level l ring: the lane's two columns of each band
@@ -319,8 +333,7 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
         }
     }
 
-    float* const tr = trash + (size_t)(blockIdx.x & 255) * 1024 + (threadIdx.x >> 6) * 256 + lane * 4;
-    float* const obase = out + 2 * (size_t)(valid ? cx1 : 0);
+    float* const tr = trash + (size_t)(blockIdx.x & 7) * Nc;  // a trash ROW (the dispatcher checks the area holds 8 of them)
 
     // one output row of level l from the ring window starting at slot S0 with tap parity OFF (cf. k_inv2d_stream::emit)
     auto emit = [&](auto S0, auto OFF, int g) {
@@ -389,8 +402,8 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
             pair_out(std::integral_constant<int, 1>{});
             single_out(std::integral_constant<int, 3>{});
         }
-        const bool st = valid && (g >= 0) && (g < 2 * rows1);
-        asm_store(st ? obase + (size_t)wrap1(2 * ya + g, Nr) * Nc : tr, v4f{o4[0], o4[1], o4[2], o4[3]});
+        const bool own = (g >= 0) && (g < 2 * rows1);  // uniform: rows of the ring warm-up / beyond the chunk go to a trash row
+        asm_store_sm(own ? out + (size_t)wrap1(2 * ya + g, Nr) * Nc : tr, voffo, v4f{o4[0], o4[1], o4[2], o4[3]}, vmask);
     };
 
     // one row of A_l (the lane's two columns) from the level-(l+1) ring window starting at slot S0, tap parity OFF
@@ -442,11 +455,11 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
         r2av[(H2 - 1 + p) % H2] = v2f{q2[p][0], q2[p][2]};
         r2hd[(H2 - 1 + p) % H2] = v2f{q2[p][1], q2[p][3]};
         {
-            const size_t o = off2(2 * H2 - 1 + s);  // the row this step needs one super-body ahead
-            asm_load(q2[p][0], pA2 + o);
-            asm_load(q2[p][1], pH2 + o);
-            asm_load(q2[p][2], pV2 + o);
-            asm_load(q2[p][3], pD2 + o);
+            const size_t o = off2(min(2 * H2 - 1 + s, H2 - 2 + nsteps));  // the row this step needs one super-body ahead (clamped to the last one)
+            asm_load_s(q2[p][0], b.A2 + o, voff2);
+            asm_load_s(q2[p][1], b.H2 + o, voff2);
+            asm_load_s(q2[p][2], b.V2 + o, voff2);
+            asm_load_s(q2[p][3], b.D2 + o, voff2);
         }
         static_for<2>([&](auto I) {
             constexpr int idx = decltype(I)::value;  // 0: tap parity 1 (A_l row 2P-SHIFT), 1: parity 0 (the next row)
@@ -461,10 +474,10 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
             rv[q % H2] = q1[q][1];
             rd[q % H2] = q1[q][2];
             {
-                const size_t o = off1(r1 + HLEN);
-                asm_load(q1[q][0], pH1 + o);
-                asm_load(q1[q][1], pV1 + o);
-                asm_load(q1[q][2], pD1 + o);
+                const size_t o = off1(min(r1 + HLEN, 2 * nsteps - 1));
+                asm_load_s(q1[q][0], b.H1 + o, voff1);
+                asm_load_s(q1[q][1], b.V1 + o, voff1);
+                asm_load_s(q1[q][2], b.D1 + o, voff1);
             }
             const int g1 = 2 * (r1 - (H2 - 1)) - SHIFT;
             emit(std::integral_constant<int, (q + 1) % H2>{}, std::integral_constant<int, 1>{}, g1);
@@ -553,7 +566,7 @@ int fwd2d_casc_f32(const float* in, float* H1, float* V1, float* D1, float* A2, 
 {
     if (!casc_enabled() || !stream_enabled() || !trash) return 1;
     if ((nr & 3) || (nc & 3) || nc < 256 || nr < 16 * hlen) return 1;
-    if ((long long)nr * nc < (long long)env_int("PDWT_CASC_MIN", 1024 * 1024)) return 1;
+    if ((long long)nr * nc < (long long)env_int("PDWT_CASC_MIN", 2048 * 2048)) return 1;
     if (!al16(in) || !al16(H1) || !al16(V1) || !al16(D1) || !al16(A2) || !al16(H2) || !al16(V2) || !al16(D2)) return 1;
     const CascBands b = {H1, V1, D1, A2, H2, V2, D2};
     switch (hlen) {
@@ -590,7 +603,7 @@ int inv2d_casc_f32(const float* A2, const float* H2, const float* V2, const floa
 {
     if (!casc_enabled() || !stream_enabled() || !trash) return 1;
     if ((nr & 3) || (nc & 3) || nc < 256 || nr < 32 * hlen) return 1;
-    if ((long long)nr * nc < (long long)env_int("PDWT_CASC_MIN", 1024 * 1024)) return 1;
+    if ((long long)nr * nc < (long long)env_int("PDWT_CASC_MIN", 2048 * 2048)) return 1;
     if (!al16(out) || !al16(H1) || !al16(V1) || !al16(D1) || !al16(A2) || !al16(H2) || !al16(V2) || !al16(D2) || !al16(trash)) return 1;
     const CascInvBands b = {A2, H2, V2, D2, H1, V1, D1};
     switch (hlen) {

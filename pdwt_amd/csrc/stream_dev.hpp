@@ -97,6 +97,41 @@ __device__ __forceinline__ void asm_load(float& d, const float* p) { asm volatil
 __device__ __forceinline__ void asm_store(float* p, v2f d) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(d) : "memory"); }
 __device__ __forceinline__ void asm_store(float* p, float d) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(d) : "memory"); }
 __device__ __forceinline__ void asm_store(float* p, v4f d) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(d) : "memory"); }
+// SGPR-base forms: address = uniform 64-bit base (SGPR pair, computed on the scalar unit) + per-lane 32-bit byte
+// offset (a loop-invariant VGPR) -> no vector ALU work per access.  The masked stores run with EXEC = `mask`
+// (lanes that own no output are switched off instead of being redirected); a partially masked VMEM instruction
+// still counts as one in vmcnt, so the hand-counted waits stay exact.
+typedef unsigned long long lanemask_t;
+__device__ __forceinline__ void asm_load_s(v4f& d, const float* sbase, unsigned voff)
+{
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void asm_load_s(v2f& d, const float* sbase, unsigned voff)
+{
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void asm_load_s(float& d, const float* sbase, unsigned voff)
+{
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void asm_store_sm(float* sbase, unsigned voff, v2f d, lanemask_t mask)
+{
+    lanemask_t saved;
+    asm volatile("s_and_saveexec_b64 %0, %4\n\tglobal_store_dwordx2 %1, %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(voff), "v"(d), "s"(sbase), "s"(mask) : "memory", "scc");
+}
+__device__ __forceinline__ void asm_store_sm(float* sbase, unsigned voff, float d, lanemask_t mask)
+{
+    lanemask_t saved;
+    asm volatile("s_and_saveexec_b64 %0, %4\n\tglobal_store_dword %1, %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(voff), "v"(d), "s"(sbase), "s"(mask) : "memory", "scc");
+}
+__device__ __forceinline__ void asm_store_sm(float* sbase, unsigned voff, v4f d, lanemask_t mask)
+{
+    lanemask_t saved;
+    asm volatile("s_and_saveexec_b64 %0, %4\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_nop 1\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(voff), "v"(d), "s"(sbase), "s"(mask) : "memory", "scc");
+}
 template <int N, typename V>
 __device__ __forceinline__ void asm_wait2(V& a, V& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
 template <int N, typename V>
