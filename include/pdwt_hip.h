@@ -180,6 +180,39 @@ int pdwt_norm1_f64(double** d_coeffs, pdwt_info info, double* out);
 int pdwt_norm1_as_double_f32(float** d_coeffs, pdwt_info info, double* out);
 int pdwt_norm1_as_double_f64(double** d_coeffs, pdwt_info info, double* out);
 
+/* ---------------------------------------------------------------------------------------------
+ * Remaining coefficient utilities of the class and the circular shift of
+ * cycle spinning (row 2).  All in place on the band table, ONE launch each.
+ *   hard_thresh       <- w_call_hard_thresh  src/common.cu:252-283 (+ kernels :57-94): v if |v| > beta else 0*v.
+ *                        As in the reference the approximation band is thresholded with the UN-normalised beta
+ *                        (it computes beta/sqrt(2)^L but passes beta, :262-270).
+ *   proj_linf         <- w_call_proj_linf  src/common.cu:286-315 (+ :96-131): copysign(min(|v|,beta),v).
+ *   shrink            <- w_shrink  src/common.cu:346-371 (3L+1 cublas scal): v / (1+beta).
+ *   group_soft_thresh <- w_call_group_soft_thresh  src/common.cu:318-343 (+ :134-198): per position
+ *                        r = max(1 - beta/||(h,v,d[,a])||_2, 0) (0 when the norm is 0), applied to h,v,d[,a];
+ *                        the approximation joins the group at the last scale only (do_thresh_appcoeffs).
+ *   norm2sq           <- Wavelets::norm2sq  src/wt.cu:370-395 (3L+1 cublas nrm2): sum of c^2 over all bands.
+ *                        The reference's 1-D branch adds cublas_asum (sum |c|) of the detail bands (:389);
+ *                        reproduced.  Accumulated in double, rounded once.
+ *   add_coeffs        <- w_add_coeffs / w_add_coeffs_1d  src/common.cu:499-526 (3L+1 cublas axpy):
+ *                        dst[k] += alpha*src[k] for every band (whole bands, also for odd sizes in 1-D where
+ *                        the reference's Nc/2 sizing leaves the last column of each band out).
+ *   circshift         <- w_call_circshift + w_kern_circshift  src/common.cu:202-211,378-396:
+ *                        out[y][x] = in[(y-sr) mod Nr][(x-sc) mod Nc] (sr forced to 0 for ndims 1); inplace != 0
+ *                        leaves the result in d_image (d_image2 is the copy), else in d_image2.
+ * ------------------------------------------------------------------------------------------- */
+#define PDWT_DECL_UTILS(T, S)                                                                                   \
+    int pdwt_hard_thresh_##S(T** d_coeffs, T beta, pdwt_info info, int do_thresh_appcoeffs, int normalize);     \
+    int pdwt_proj_linf_##S(T** d_coeffs, T beta, pdwt_info info, int do_thresh_appcoeffs);                      \
+    int pdwt_shrink_##S(T** d_coeffs, T beta, pdwt_info info, int do_thresh_appcoeffs);                         \
+    int pdwt_group_soft_thresh_##S(T** d_coeffs, T beta, pdwt_info info, int do_thresh_appcoeffs, int normalize); \
+    int pdwt_norm2sq_##S(T** d_coeffs, pdwt_info info, T* out);                                                 \
+    int pdwt_norm2sq_as_double_##S(T** d_coeffs, pdwt_info info, double* out);                                  \
+    int pdwt_add_coeffs_##S(T** d_dst, T** d_src, pdwt_info info, T alpha);                                     \
+    int pdwt_circshift_##S(T* d_image, T* d_image2, pdwt_info info, int sr, int sc, int inplace);
+PDWT_DECL_UTILS(float, f32)
+PDWT_DECL_UTILS(double, f64)
+
 #ifdef __cplusplus
 }
 #endif

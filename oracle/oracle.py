@@ -185,6 +185,134 @@ class OracleWavelets:
     def norm1_f64(self):
         return float(getattr(lib(), "orc_norm1_" + self.sfx)(self._ctab, self.info))
 
+    # -- remaining coefficient utilities: numpy restatements, elementwise in DTYPE ----------
+    def _band(self, num):
+        """writable view of the coefficients of band `num`"""
+        r, c = self.shapes[num]
+        return self._bufs[num][: r * c]
+
+    def _walk(self, beta, do_thresh_appcoeffs, normalize, app_normalized):
+        """Band walk shared by w_call_{soft,hard}_thresh / w_call_proj_linf / w_shrink (src/common.cu:219-315):
+        yields (band view, beta for that band); beta is divided by sqrt(2) per level when normalize > 0, the
+        approximation band takes beta/sqrt(2)^L only where the reference really passes it (soft threshold)."""
+        T = self.dtype.type
+        beta = T(beta)
+        per = 3 if self.info.ndims == 2 else 1
+        L = self.info.nlevels
+        if do_thresh_appcoeffs:
+            beta2 = beta
+            if normalize > 0 and app_normalized:  # src/common.cu:231-235
+                nl2 = L // 2
+                beta2 = T(beta2 / T(1 << nl2))
+                if nl2 * 2 != L:
+                    beta2 = T(np.float64(beta2) / 1.4142135623730951)
+            yield self._band(0), beta2
+        for lev in range(L):
+            if normalize > 0:
+                beta = T(np.float64(beta) / 1.4142135623730951)  # src/common.cu:244
+            for b in range(per):
+                yield self._band(per * lev + 1 + b), beta
+
+    def hard_threshold(self, beta, do_thresh_appcoeffs=0, normalize=0):  # src/wt.cu:320-327, common.cu:57-94, 252-283
+        if self.state == W_INVERSE:
+            return
+        # the approximation band gets the UN-normalised beta (common.cu:270 passes beta, not beta2)
+        for v, b in self._walk(beta, do_thresh_appcoeffs, normalize, app_normalized=False):
+            v *= (np.abs(v) - b > 0).astype(self.dtype)  # max(W_SIGN(|v|-b), 0) * v
+
+    def proj_linf(self, beta, do_thresh_appcoeffs=1):  # src/wt.cu:350-357, common.cu:96-131, 286-315
+        if self.state == W_INVERSE:
+            return
+        for v, b in self._walk(beta, do_thresh_appcoeffs, 0, app_normalized=False):
+            v[...] = np.copysign(np.minimum(np.abs(v), b), v)
+
+    def shrink(self, beta, do_thresh_appcoeffs=1):  # src/wt.cu:341-348, common.cu:346-371: scal by 1/(1+beta)
+        if self.state == W_INVERSE:
+            return
+        T = self.dtype.type
+        f = T(T(1) / (T(1) + T(beta)))
+        for v, _ in self._walk(beta, do_thresh_appcoeffs, 0, app_normalized=False):
+            v *= f
+
+    def group_soft_threshold(self, beta, do_thresh_appcoeffs=0, normalize=0):  # src/wt.cu:331-338, common.cu:134-198, 318-343
+        if self.state == W_INVERSE:
+            return
+        T = self.dtype.type
+        beta = T(beta)
+        per = 3 if self.info.ndims == 2 else 1
+        L = self.info.nlevels
+        for lev in range(L):
+            if normalize > 0:
+                beta = T(np.float64(beta) / 1.4142135623730951)
+            bands = [self._band(per * lev + 1 + b) for b in range(per)]
+            if do_thresh_appcoeffs and lev == L - 1:
+                bands.append(self._band(0))
+            nrm = np.zeros_like(bands[0])
+            for v in bands:
+                nrm += v * v
+            nrm = np.sqrt(nrm)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                res = np.where(nrm == 0, T(0), np.maximum(T(1) - beta / nrm, T(0))).astype(self.dtype)
+            for v in bands:
+                v *= res
+
+    def norm2sq(self):  # src/wt.cu:370-395 (1-D branch: asum of the details, as written there)
+        acc = 0.0
+        for k in range(len(self.shapes)):
+            v = self._band(k).astype(np.float64)
+            if self.info.ndims == 1 and k > 0:
+                acc += np.abs(v).sum()
+            else:
+                acc += (v * v).sum()
+        return self.dtype.type(acc)
+
+    def add_wavelet(self, other, alpha=1.0):  # src/wt.cu:624-657, common.cu:499-526 (whole bands)
+        if self.info.nlevels != other.info.nlevels or self.wname.lower() != other.wname.lower():
+            return -1
+        if self.state == W_INVERSE or other.state == W_INVERSE:
+            return 1
+        if (self.info.Nr, self.info.Nc, self.info.ndims) != (other.info.Nr, other.info.Nc, other.info.ndims):
+            return -2
+        if bool(self.info.do_swt) != bool(other.info.do_swt):
+            return -3
+        a = self.dtype.type(alpha)
+        for k in range(len(self.shapes)):
+            self._band(k)[...] += a * other._band(k)
+        return 0
+
+    def circshift(self, sr, sc, inplace=1):  # src/wt.cu:364-366, common.cu:202-211, 378-396
+        Nr, Nc = self.info.Nr, self.info.Nc
+        if self.info.ndims == 1:
+            sr = 0
+        out = np.roll(self.image, (sr % Nr, sc % Nc), axis=(0, 1))
+        if inplace:
+            self.image[...] = out
+        else:
+            self.tmp[: Nr * Nc] = out.reshape(-1)
+
+    def set_filters_forward(self, name, lo, hi):  # src/wt.cu:560-581
+        lo = np.asarray(lo, dtype=self.dtype)
+        hi = np.asarray(hi, dtype=self.dtype)
+        if lo.size > 40:
+            return -1
+        if self._F is None:
+            self._F = Filters32() if self.dtype == np.float32 else Filters64()
+        for i in range(40):
+            self._F.L[i] = lo[i] if i < lo.size else 0
+            self._F.H[i] = hi[i] if i < hi.size else 0
+        self._F.hlen = lo.size
+        self.info.hlen = lo.size
+        self.wname = name
+        return 0
+
+    def set_filters_inverse(self, lo, hi):  # src/wt.cu:584-602
+        lo = np.asarray(lo, dtype=self.dtype)
+        hi = np.asarray(hi, dtype=self.dtype)
+        for i in range(40):
+            self._F.IL[i] = lo[i] if i < lo.size else 0
+            self._F.IH[i] = hi[i] if i < hi.size else 0
+        return 0
+
     def get_image(self):  # src/wt.cu:421-424
         return self.image.copy()
 

@@ -40,7 +40,8 @@ PLAIN_SYMBOLS = ["pdwt_device_count", "pdwt_set_device", "pdwt_get_device", "pdw
                  "pdwt_event_destroy", "pdwt_ktime_enable", "pdwt_ktime_reset", "pdwt_ktime_read", "pdwt_kernel_name",
                  "pdwt_kernel_count", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set"]
 TYPED_SYMBOLS = (["compute_filters_separable", "create_coeffs_buffer", "free_coeffs_buffer", "copy_coeffs_buffer",
-                  "soft_thresh", "norm1", "norm1_as_double"] + DRIVERS + HAAR_DRIVERS)
+                  "soft_thresh", "norm1", "norm1_as_double", "hard_thresh", "proj_linf", "shrink", "group_soft_thresh",
+                  "norm2sq", "norm2sq_as_double", "add_coeffs", "circshift"] + DRIVERS + HAAR_DRIVERS)
 
 _hip = None
 _host = {}
@@ -98,6 +99,14 @@ def hip():
         getattr(L, "pdwt_soft_thresh_" + sfx).argtypes = [PP, ct, Info, ci, ci]
         getattr(L, "pdwt_norm1_" + sfx).argtypes = [PP, Info, P]
         getattr(L, "pdwt_norm1_as_double_" + sfx).argtypes = [PP, Info, C.POINTER(C.c_double)]
+        for n in ("hard_thresh", "group_soft_thresh"):
+            getattr(L, "pdwt_%s_%s" % (n, sfx)).argtypes = [PP, ct, Info, ci, ci]
+        for n in ("proj_linf", "shrink"):
+            getattr(L, "pdwt_%s_%s" % (n, sfx)).argtypes = [PP, ct, Info, ci]
+        getattr(L, "pdwt_norm2sq_" + sfx).argtypes = [PP, Info, P]
+        getattr(L, "pdwt_norm2sq_as_double_" + sfx).argtypes = [PP, Info, C.POINTER(C.c_double)]
+        getattr(L, "pdwt_add_coeffs_" + sfx).argtypes = [PP, PP, Info, ct]
+        getattr(L, "pdwt_circshift_" + sfx).argtypes = [vp, vp, Info, ci, ci, ci]
         for d in DRIVERS:
             getattr(L, "pdwt_%s_%s" % (d, sfx)).argtypes = [vp, PP, vp, Info, C.POINTER(FT)]
         for d in HAAR_DRIVERS:
@@ -126,6 +135,17 @@ def host(dtype):
         L.pdwt_wavelets_soft_threshold.argtypes = [vp, ct, ci, ci]
         L.pdwt_wavelets_norm1.restype = ct
         L.pdwt_wavelets_norm1.argtypes = [vp]
+        L.pdwt_wavelets_norm2sq.restype = ct
+        L.pdwt_wavelets_norm2sq.argtypes = [vp]
+        for n in ("hard_threshold", "group_soft_threshold"):
+            getattr(L, "pdwt_wavelets_" + n).argtypes = [vp, ct, ci, ci]
+        for n in ("shrink", "proj_linf"):
+            getattr(L, "pdwt_wavelets_" + n).argtypes = [vp, ct, ci]
+        L.pdwt_wavelets_circshift.argtypes = [vp, ci, ci, ci]
+        L.pdwt_wavelets_set_filters_forward.argtypes = [vp, C.c_char_p, C.c_uint, vp, vp]
+        L.pdwt_wavelets_set_filters_inverse.argtypes = [vp, vp, vp]
+        L.pdwt_wavelets_add_wavelet.argtypes = [vp, vp, ct]
+        L.pdwt_wavelets_shifts.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
         L.pdwt_wavelets_get_image.argtypes = [vp, vp]
         L.pdwt_wavelets_set_image.argtypes = [vp, vp, ci]
         L.pdwt_wavelets_get_coeff.argtypes = [vp, vp, ci]

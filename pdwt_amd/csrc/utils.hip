@@ -1,6 +1,11 @@
-// utils.hip -- coefficient utilities on the hot path: soft threshold and L1 norm.
+// utils.hip -- coefficient utilities: thresholds / projections / scaling, norms, coefficient axpy, circular shift.
 //
 // Path replaced:
+//   hard / group-soft threshold, proj_linf, shrink   reference w_call_hard_thresh, w_call_group_soft_thresh,
+//                   w_call_proj_linf, w_shrink (src/common.cu:57-198, 252-371): L (+1) launches (or 3L+1 cuBLAS scal)
+//   norm2sq         reference Wavelets::norm2sq (src/wt.cu:370-395): 3L+1 cuBLAS nrm2 calls
+//   add_coeffs      reference w_add_coeffs{,_1d} (src/common.cu:499-526): 3L+1 cuBLAS axpy calls
+//   circshift       reference w_kern_circshift + w_call_circshift (src/common.cu:202-211, 378-396)
 //   soft threshold  reference w_call_soft_thresh + w_kern_soft_thresh{,_1d,_appcoeffs}
 //                   (src/common.cu:13-52, 219-249): L (+1) launches of 16x16-thread blocks.
 //   norm1           reference Wavelets::norm1 (src/wt.cu:398-418): 3L+1 cuBLAS asum calls, each a
@@ -35,10 +40,29 @@ template <typename T> struct V16;
 template <> struct V16<float> { using type = float4; static constexpr int N = 4; };
 template <> struct V16<double> { using type = double2; static constexpr int N = 2; };
 
-template <typename T> __device__ __forceinline__ T soft1(T x, T beta);
+// elementwise operators of the threshold family; `b` is the per-band parameter of the table
+enum EwOp { OP_SOFT = 0, OP_HARD, OP_PROJ, OP_SCALE };
+__device__ __forceinline__ float abs_t(float x) { return fabsf(x); }
+__device__ __forceinline__ double abs_t(double x) { return fabs(x); }
+__device__ __forceinline__ float copysign_t(float a, float s) { return copysignf(a, s); }
+__device__ __forceinline__ double copysign_t(double a, double s) { return copysign(a, s); }
 // type-correct forms (the reference calls fabsf/copysignf even in the double build, SURVEY B-3)
-template <> __device__ __forceinline__ float soft1<float>(float x, float b) { return copysignf(fmaxf(fabsf(x) - b, 0.0f), x); }
-template <> __device__ __forceinline__ double soft1<double>(double x, double b) { return copysign(fmax(fabs(x) - b, 0.0), x); }
+template <int OP, typename T>
+__device__ __forceinline__ T ew_op(T x, T b)
+{
+    if constexpr (OP == OP_SOFT) {  // src/common.cu:19: copysign(max(|x|-b, 0), x)
+        const T m = abs_t(x) - b;
+        return copysign_t(m > T(0) ? m : T(0), x);
+    } else if constexpr (OP == OP_HARD) {  // src/common.cu:63: max(W_SIGN(|x|-b), 0)*x  -> x if |x| > b, else 0*x (keeps the sign of zero)
+        return (abs_t(x) - b > T(0) ? T(1) : T(0)) * x;
+    } else if constexpr (OP == OP_PROJ) {  // src/common.cu:107: copysign(min(|x|, b), x)
+        const T a = abs_t(x);
+        return copysign_t(a < b ? a : b, x);
+    } else {  // OP_SCALE, cublas scal: x * b
+        return x * b;
+    }
+}
+template <typename T> __device__ __forceinline__ T soft1(T x, T beta) { return ew_op<OP_SOFT, T>(x, beta); }
 
 __device__ __forceinline__ int find_band(const unsigned int* chunk0, int nb, unsigned int chunk)
 {
@@ -47,7 +71,7 @@ __device__ __forceinline__ int find_band(const unsigned int* chunk0, int nb, uns
     return k;
 }
 
-template <typename T, bool VEC>
+template <typename T, bool VEC, int OP>
 __global__ __launch_bounds__(kUThreads) void k_soft_thresh(BandTable<T> tab)
 {
     const unsigned int total = tab.chunk0[tab.nb];
@@ -67,16 +91,16 @@ __global__ __launch_bounds__(kUThreads) void k_soft_thresh(BandTable<T> tab)
                     V v = *reinterpret_cast<V*>(p + i);
                     T* e = reinterpret_cast<T*>(&v);
 #pragma unroll
-                    for (int q = 0; q < NV; q++) e[q] = soft1<T>(e[q], beta);
+                    for (int q = 0; q < NV; q++) e[q] = ew_op<OP, T>(e[q], beta);
                     *reinterpret_cast<V*>(p + i) = v;
                 } else {
-                    for (unsigned long long j = i; j < n; j++) p[j] = soft1<T>(p[j], beta);
+                    for (unsigned long long j = i; j < n; j++) p[j] = ew_op<OP, T>(p[j], beta);
                 }
             }
         } else {
             for (int u = 0; u < kChunk / kUThreads; u++) {
                 const unsigned long long i = base + (unsigned long long)u * kUThreads + threadIdx.x;
-                if (i < n) p[i] = soft1<T>(p[i], beta);
+                if (i < n) p[i] = ew_op<OP, T>(p[i], beta);
             }
         }
     }
@@ -99,6 +123,7 @@ __global__ __launch_bounds__(kUThreads) void k_abs_sum(BandTable<T> tab, double*
         const int k = find_band(tab.chunk0, tab.nb, chunk);
         const T* __restrict__ p = tab.ptr[k];
         const unsigned long long n = tab.n[k];
+        const bool sq = tab.beta[k] != T(0);  // per-band mode: 0 -> sum |x| (norm1), else sum x^2 (norm2sq)
         const unsigned long long base = (unsigned long long)(chunk - tab.chunk0[k]) * kChunk;
         if constexpr (VEC) {
             using V = typename V16<T>::type;
@@ -110,15 +135,15 @@ __global__ __launch_bounds__(kUThreads) void k_abs_sum(BandTable<T> tab, double*
                     const V v = *reinterpret_cast<const V*>(p + i);
                     const T* e = reinterpret_cast<const T*>(&v);
 #pragma unroll
-                    for (int q = 0; q < NV; q++) acc += (double)(e[q] < 0 ? -e[q] : e[q]);
+                    for (int q = 0; q < NV; q++) acc += sq ? (double)e[q] * (double)e[q] : (double)(e[q] < 0 ? -e[q] : e[q]);
                 } else {
-                    for (unsigned long long j = i; j < n; j++) acc += (double)(p[j] < 0 ? -p[j] : p[j]);
+                    for (unsigned long long j = i; j < n; j++) acc += sq ? (double)p[j] * (double)p[j] : (double)(p[j] < 0 ? -p[j] : p[j]);
                 }
             }
         } else {
             for (int u = 0; u < kChunk / kUThreads; u++) {
                 const unsigned long long i = base + (unsigned long long)u * kUThreads + threadIdx.x;
-                if (i < n) acc += (double)(p[i] < 0 ? -p[i] : p[i]);
+                if (i < n) acc += sq ? (double)p[i] * (double)p[i] : (double)(p[i] < 0 ? -p[i] : p[i]);
             }
         }
     }
@@ -138,6 +163,106 @@ __global__ __launch_bounds__(kUThreads) void k_abs_sum_final(const double* __res
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) out[0] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+// group soft threshold (src/common.cu:134-198): one scale factor per position from the l2 norm of the
+// detail coefficients there (and of the approximation at the last scale when asked), applied to all of them.
+template <typename T>
+struct GroupTable {
+    T* h[32];
+    T* v[32];
+    T* d[32];
+    T* a[32];  // NULL except at the last scale with do_thresh_appcoeffs
+    unsigned long long n[32];
+    unsigned int chunk0[33];
+    T beta[32];
+    int nb;
+};
+__device__ __forceinline__ float sqrt_t(float x) { return sqrtf(x); }
+__device__ __forceinline__ double sqrt_t(double x) { return sqrt(x); }  // (the reference calls sqrtf in the double build too, B-3)
+
+template <typename T>
+__global__ __launch_bounds__(kUThreads) void k_group_soft_thresh(GroupTable<T> tab)
+{
+    const unsigned int total = tab.chunk0[tab.nb];
+    for (unsigned int chunk = blockIdx.x; chunk < total; chunk += gridDim.x) {
+        const int k = find_band(tab.chunk0, tab.nb, chunk);
+        T* __restrict__ ph = tab.h[k];
+        T* __restrict__ pv = tab.v[k];
+        T* __restrict__ pd = tab.d[k];
+        T* __restrict__ pa = tab.a[k];
+        const unsigned long long n = tab.n[k];
+        const T beta = tab.beta[k];
+        const unsigned long long base = (unsigned long long)(chunk - tab.chunk0[k]) * kChunk;
+        for (int u = 0; u < kChunk / kUThreads; u++) {
+            const unsigned long long i = base + (unsigned long long)u * kUThreads + threadIdx.x;
+            if (i < n) {
+                const T vd = pd[i];
+                const T vh = ph ? ph[i] : T(0), vv = pv ? pv[i] : T(0);
+                // same association as the reference: h*h + v*v + d*d (+ a*a), plain products (no contraction across
+                // the sum in the reference's nvcc build would change nothing beyond 1 ulp of the norm)
+                T nrm = ph ? vh * vh + vv * vv + vd * vd : vd * vd;
+                T va = T(0);
+                if (pa) {
+                    va = pa[i];
+                    nrm += va * va;
+                }
+                nrm = sqrt_t(nrm);
+                T res = T(0);
+                if (nrm != T(0)) {
+                    res = T(1) - beta / nrm;
+                    if (!(res > T(0))) res = T(0);
+                }
+                if (ph) {
+                    ph[i] = vh * res;
+                    pv[i] = vv * res;
+                }
+                pd[i] = vd * res;
+                if (pa) pa[i] = va * res;
+            }
+        }
+    }
+}
+
+// dst += alpha * src over a table of band pairs (cublas axpy per band in the reference)
+template <typename T>
+struct PairTable {
+    T* dst[kMaxBands];
+    const T* src[kMaxBands];
+    unsigned long long n[kMaxBands];
+    unsigned int chunk0[kMaxBands + 1];
+    int nb;
+};
+template <typename T>
+__global__ __launch_bounds__(kUThreads) void k_axpy_bands(PairTable<T> tab, T alpha)
+{
+    const unsigned int total = tab.chunk0[tab.nb];
+    for (unsigned int chunk = blockIdx.x; chunk < total; chunk += gridDim.x) {
+        const int k = find_band(tab.chunk0, tab.nb, chunk);
+        T* __restrict__ d = tab.dst[k];
+        const T* __restrict__ sp = tab.src[k];
+        const unsigned long long n = tab.n[k];
+        const unsigned long long base = (unsigned long long)(chunk - tab.chunk0[k]) * kChunk;
+        for (int u = 0; u < kChunk / kUThreads; u++) {
+            const unsigned long long i = base + (unsigned long long)u * kUThreads + threadIdx.x;
+            if (i < n) d[i] = fma_t<T>(alpha, sp[i], d[i]);
+        }
+    }
+}
+
+// out[y][x] = in[(y - sr) mod Nr][(x - sc) mod Nc], 0 <= sr < Nr, 0 <= sc < Nc  (src/common.cu:202-211)
+template <typename T>
+__global__ __launch_bounds__(kUThreads) void k_circshift(const T* __restrict__ in, T* __restrict__ out, int Nr, int Nc, int sr, int sc)
+{
+    const int x = blockIdx.x * kUThreads + threadIdx.x;
+    if (x >= Nc) return;
+    int c = x - sc;
+    if (c < 0) c += Nc;
+    for (int y = blockIdx.y; y < Nr; y += gridDim.y) {
+        int r = y - sr;
+        if (r < 0) r += Nr;
+        out[(size_t)y * Nc + x] = in[(size_t)r * Nc + c];
+    }
 }
 
 #define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
@@ -169,9 +294,12 @@ static bool table_push(BandTable<T>& t, T* p, size_t n, T beta, bool& vec_ok)
     return true;
 }
 
-// w_call_soft_thresh, src/common.cu:219-249
-template <typename T>
-static int soft_thresh(T** c, T beta, pdwt_info w, int do_thresh_appcoeffs, int normalize)
+// w_call_soft_thresh / w_call_hard_thresh / w_call_proj_linf / w_shrink, src/common.cu:219-315, 346-371: the same
+// band walk with a different elementwise operator.  normalize: beta / sqrt(2) per level (soft, hard);
+// the approximation band takes beta / sqrt(2)^nlevels (soft) -- or, for the HARD threshold, the un-normalised
+// beta: the reference computes beta2 but passes beta (src/common.cu:262-270, SURVEY B-4), reproduced.
+template <int OP, typename T>
+static int ew_bands(T** c, T beta, pdwt_info w, int do_thresh_appcoeffs, int normalize, int kernel_id)
 {
     if (!c) return PDWT_EINVAL;
     BandGeom g;
@@ -181,19 +309,20 @@ static int soft_thresh(T** c, T beta, pdwt_info w, int do_thresh_appcoeffs, int 
     tab.chunk0[0] = 0;
     bool vec = true;
     const int per = (w.ndims == 2) ? 3 : 1;
+    if (OP == OP_SCALE) beta = T(1) / (T(1) + beta);  // w_shrink: scal by 1/(1+beta), src/common.cu:355
     if (do_thresh_appcoeffs) {
         T beta2 = beta;
-        if (normalize > 0) {  // beta / sqrt(2)^nlevels, src/common.cu:231-235
+        if (normalize > 0 && OP == OP_SOFT) {  // beta / sqrt(2)^nlevels, src/common.cu:231-235
             const int nl2 = w.nlevels / 2;
             beta2 /= (T)(1 << nl2);
             if (nl2 * 2 != w.nlevels) beta2 = (T)(beta2 / 1.4142135623730951);
         }
         // the reference sweeps the whole level-1-sized allocation of band 0; only its first
-        // Nr_L*Nc_L elements are coefficients, the rest is scratch -> threshold the coefficients only
+        // Nr_L*Nc_L elements are coefficients, the rest is scratch -> process the coefficients only
         if (!table_push<T>(tab, c[0], (size_t)g.Nr[0] * g.Nc[0], beta2, vec)) return PDWT_EINVAL;
     }
     for (int lev = 0; lev < w.nlevels; lev++) {
-        if (normalize > 0) beta = (T)(beta / 1.4142135623730951);  // src/common.cu:244
+        if (normalize > 0 && (OP == OP_SOFT || OP == OP_HARD)) beta = (T)(beta / 1.4142135623730951);  // src/common.cu:244,277
         for (int b = 0; b < per; b++) {
             const int k = per * lev + 1 + b;
             if (!table_push<T>(tab, c[k], (size_t)g.Nr[k] * g.Nc[k], beta, vec)) return PDWT_EINVAL;
@@ -202,16 +331,53 @@ static int soft_thresh(T** c, T beta, pdwt_info w, int do_thresh_appcoeffs, int 
     const unsigned int total = tab.chunk0[tab.nb];
     if (total == 0) return PDWT_OK;
     const int blocks = (int)(total < (unsigned)kMaxBlocks ? total : (unsigned)kMaxBlocks);
-    KTimer kt(K_SOFT_THRESH);
-    if (vec) hipLaunchKernelGGL((k_soft_thresh<T, true>), dim3(blocks), dim3(kUThreads), 0, stream(), tab);
-    else hipLaunchKernelGGL((k_soft_thresh<T, false>), dim3(blocks), dim3(kUThreads), 0, stream(), tab);
+    KTimer kt(kernel_id);
+    if (vec) hipLaunchKernelGGL((k_soft_thresh<T, true, OP>), dim3(blocks), dim3(kUThreads), 0, stream(), tab);
+    else hipLaunchKernelGGL((k_soft_thresh<T, false, OP>), dim3(blocks), dim3(kUThreads), 0, stream(), tab);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
 
-// Wavelets::norm1, src/wt.cu:398-418: sum of |c| over all bands including band 0
+// w_call_group_soft_thresh, src/common.cu:318-343
 template <typename T>
-static int norm1_double(T** c, pdwt_info w, double* out)
+static int group_soft_thresh(T** c, T beta, pdwt_info w, int do_thresh_appcoeffs, int normalize)
+{
+    if (!c) return PDWT_EINVAL;
+    BandGeom g;
+    if (band_geometry(w, &g) != PDWT_OK || w.nlevels > 32) return PDWT_EINVAL;
+    GroupTable<T> tab;
+    tab.nb = 0;
+    tab.chunk0[0] = 0;
+    const int per = (w.ndims == 2) ? 3 : 1;
+    for (int lev = 0; lev < w.nlevels; lev++) {
+        if (normalize > 0) beta = (T)(beta / 1.4142135623730951);
+        const int k0 = per * lev + 1;
+        const size_t n = (size_t)g.Nr[k0] * g.Nc[k0];
+        const int k = tab.nb++;
+        tab.h[k] = (per == 3) ? c[k0] : nullptr;
+        tab.v[k] = (per == 3) ? c[k0 + 1] : nullptr;
+        tab.d[k] = (per == 3) ? c[k0 + 2] : c[k0];
+        // the approximation joins the group at the last scale only, where it has the size of the details
+        tab.a[k] = (do_thresh_appcoeffs && lev == w.nlevels - 1) ? c[0] : nullptr;
+        tab.n[k] = n;
+        tab.beta[k] = beta;
+        tab.chunk0[k + 1] = tab.chunk0[k] + (unsigned int)((n + kChunk - 1) / kChunk);
+    }
+    const unsigned int total = tab.chunk0[tab.nb];
+    if (total == 0) return PDWT_OK;
+    const int blocks = (int)(total < (unsigned)kMaxBlocks ? total : (unsigned)kMaxBlocks);
+    KTimer kt(K_SOFT_THRESH);
+    hipLaunchKernelGGL(k_group_soft_thresh<T>, dim3(blocks), dim3(kUThreads), 0, stream(), tab);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
+// sum over bands of |c| (mode 0) or c^2 (mode 1), in double.
+//   norm1   Wavelets::norm1, src/wt.cu:398-418: |c| over all bands including band 0
+//   norm2sq Wavelets::norm2sq, src/wt.cu:370-395: c^2 over all bands -- except that the reference's 1-D branch adds
+//           cublas_asum (sum |c|) of the detail bands (src/wt.cu:389, SURVEY B-4); reproduced when `ref_quirk_1d`.
+template <typename T>
+static int band_sum_double(T** c, pdwt_info w, double* out, int squares, int ref_quirk_1d)
 {
     if (!c || !out) return PDWT_EINVAL;
     BandGeom g;
@@ -220,8 +386,10 @@ static int norm1_double(T** c, pdwt_info w, double* out)
     tab.nb = 0;
     tab.chunk0[0] = 0;
     bool vec = true;
-    for (int k = 0; k < g.nbands; k++)
-        if (!table_push<T>(tab, c[k], (size_t)g.Nr[k] * g.Nc[k], T(0), vec)) return PDWT_EINVAL;
+    for (int k = 0; k < g.nbands; k++) {
+        const bool sq = squares && !(ref_quirk_1d && w.ndims == 1 && k > 0);
+        if (!table_push<T>(tab, c[k], (size_t)g.Nr[k] * g.Nc[k], sq ? T(1) : T(0), vec)) return PDWT_EINVAL;
+    }
     double* part = partials();
     if (!part) return PDWT_ENOMEM;
     const unsigned int total = tab.chunk0[tab.nb];
@@ -240,21 +408,96 @@ static int norm1_double(T** c, pdwt_info w, double* out)
     return pdwt_memcpy_d2h(out, part + kMaxBlocks, sizeof(double));
 }
 
+// w_add_coeffs / w_add_coeffs_1d, src/common.cu:499-526: dst += alpha*src on every band.  (The reference's 1-D
+// variant sizes the bands with Nc/2 instead of the ceil-half rule, i.e. it skips part of each band for odd
+// sizes, SURVEY B-4: fixed here, the whole band is added.)
+template <typename T>
+static int add_coeffs(T** dst, T** src, pdwt_info w, T alpha)
+{
+    if (!dst || !src) return PDWT_EINVAL;
+    BandGeom g;
+    if (band_geometry(w, &g) != PDWT_OK) return PDWT_EINVAL;
+    PairTable<T> tab;
+    tab.nb = 0;
+    tab.chunk0[0] = 0;
+    for (int k = 0; k < g.nbands; k++) {
+        if (!dst[k] || !src[k]) return PDWT_EINVAL;
+        const size_t n = (size_t)g.Nr[k] * g.Nc[k];
+        tab.dst[k] = dst[k];
+        tab.src[k] = src[k];
+        tab.n[k] = n;
+        tab.chunk0[k + 1] = tab.chunk0[k] + (unsigned int)((n + kChunk - 1) / kChunk);
+        tab.nb++;
+    }
+    const unsigned int total = tab.chunk0[tab.nb];
+    if (total == 0) return PDWT_OK;
+    const int blocks = (int)(total < (unsigned)kMaxBlocks ? total : (unsigned)kMaxBlocks);
+    KTimer kt(K_SOFT_THRESH);
+    hipLaunchKernelGGL(k_axpy_bands<T>, dim3(blocks), dim3(kUThreads), 0, stream(), tab, alpha);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
+// w_call_circshift, src/common.cu:378-396.  inplace: result in d_image (through a copy in d_image2), else in d_image2.
+template <typename T>
+static int circshift(T* d_image, T* d_image2, pdwt_info w, int sr, int sc, int inplace)
+{
+    if (!d_image || !d_image2 || w.Nr < 1 || w.Nc < 1) return PDWT_EINVAL;
+    const int Nr = w.Nr, Nc = w.Nc;
+    if (sr < 0) sr += Nr;  // (the reference normalises the same way: one add, then %; src/common.cu:381-385)
+    if (sc < 0) sc += Nc;
+    sr %= Nr;
+    sc %= Nc;
+    if (sr < 0) sr += Nr;
+    if (sc < 0) sc += Nc;
+    if (w.ndims == 1) sr = 0;
+    const T* in = d_image;
+    T* out = d_image2;
+    if (inplace) {
+        const int rc = pdwt_memcpy_d2d(d_image2, d_image, (size_t)Nr * Nc * sizeof(T));
+        if (rc != PDWT_OK) return rc;
+        in = d_image2;
+        out = d_image;
+    }
+    dim3 grid(idiv_up(Nc, kUThreads), Nr < 1024 ? Nr : 1024);
+    KTimer kt(K_SOFT_THRESH);
+    hipLaunchKernelGGL(k_circshift<T>, grid, dim3(kUThreads), 0, stream(), in, out, Nr, Nc, sr, sc);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
 }  // namespace pdwt
 
 using namespace pdwt;
 
+#define PDWT_UTILS_API(SFX, T)                                                                                                       \
+    int pdwt_soft_thresh_##SFX(T** c, T beta, pdwt_info w, int app, int norm) { return ew_bands<OP_SOFT, T>(c, beta, w, app, norm, K_SOFT_THRESH); } \
+    int pdwt_hard_thresh_##SFX(T** c, T beta, pdwt_info w, int app, int norm) { return ew_bands<OP_HARD, T>(c, beta, w, app, norm, K_SOFT_THRESH); } \
+    int pdwt_proj_linf_##SFX(T** c, T beta, pdwt_info w, int app) { return ew_bands<OP_PROJ, T>(c, beta, w, app, 0, K_SOFT_THRESH); }         \
+    int pdwt_shrink_##SFX(T** c, T beta, pdwt_info w, int app) { return ew_bands<OP_SCALE, T>(c, beta, w, app, 0, K_SOFT_THRESH); }           \
+    int pdwt_group_soft_thresh_##SFX(T** c, T beta, pdwt_info w, int app, int norm) { return group_soft_thresh<T>(c, beta, w, app, norm); }   \
+    int pdwt_norm1_as_double_##SFX(T** c, pdwt_info w, double* out) { return band_sum_double<T>(c, w, out, 0, 0); }                          \
+    int pdwt_norm2sq_as_double_##SFX(T** c, pdwt_info w, double* out) { return band_sum_double<T>(c, w, out, 1, 1); }                        \
+    int pdwt_norm1_##SFX(T** c, pdwt_info w, T* out)                                                                                         \
+    {                                                                                                                                        \
+        double d = 0;                                                                                                                        \
+        if (!out) return PDWT_EINVAL;                                                                                                        \
+        const int rc = band_sum_double<T>(c, w, &d, 0, 0);                                                                                   \
+        if (rc == PDWT_OK) *out = (T)d;                                                                                                      \
+        return rc;                                                                                                                           \
+    }                                                                                                                                        \
+    int pdwt_norm2sq_##SFX(T** c, pdwt_info w, T* out)                                                                                       \
+    {                                                                                                                                        \
+        double d = 0;                                                                                                                        \
+        if (!out) return PDWT_EINVAL;                                                                                                        \
+        const int rc = band_sum_double<T>(c, w, &d, 1, 1);                                                                                   \
+        if (rc == PDWT_OK) *out = (T)d;                                                                                                      \
+        return rc;                                                                                                                           \
+    }                                                                                                                                        \
+    int pdwt_add_coeffs_##SFX(T** dst, T** src, pdwt_info w, T alpha) { return add_coeffs<T>(dst, src, w, alpha); }                         \
+    int pdwt_circshift_##SFX(T* img, T* img2, pdwt_info w, int sr, int sc, int inplace) { return circshift<T>(img, img2, w, sr, sc, inplace); }
+
 extern "C" {
-int pdwt_soft_thresh_f32(float** c, float beta, pdwt_info w, int app, int norm) { return soft_thresh<float>(c, beta, w, app, norm); }
-int pdwt_soft_thresh_f64(double** c, double beta, pdwt_info w, int app, int norm) { return soft_thresh<double>(c, beta, w, app, norm); }
-int pdwt_norm1_as_double_f32(float** c, pdwt_info w, double* out) { return norm1_double<float>(c, w, out); }
-int pdwt_norm1_as_double_f64(double** c, pdwt_info w, double* out) { return norm1_double<double>(c, w, out); }
-int pdwt_norm1_f32(float** c, pdwt_info w, float* out)
-{
-    double d = 0;
-    int rc = norm1_double<float>(c, w, &d);
-    if (rc == PDWT_OK && out) *out = (float)d;
-    return out ? rc : PDWT_EINVAL;
-}
-int pdwt_norm1_f64(double** c, pdwt_info w, double* out) { return norm1_double<double>(c, w, out); }
+PDWT_UTILS_API(f32, float)
+PDWT_UTILS_API(f64, double)
 }

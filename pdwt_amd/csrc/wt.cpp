@@ -285,21 +285,140 @@ DTYPE Wavelets::norm1()
     return res;
 }
 
-// The remaining utilities of the reference class are not on the hot path this build replaces
-// (SURVEY.md 8f "next" rows 1-2).  They fail loudly instead of silently doing nothing.
-static void not_built(const char* what)
+// The remaining coefficient utilities (src/wt.cu:320-358): same state rule as soft_threshold.
+#define PDWT_THRESH_METHOD(NAME, CALL)                                                                         \
+    if (state == W_INVERSE) {                                                                                  \
+        puts("Warning: Wavelets(): cannot threshold coefficients, as they were modified by W.inverse()");      \
+        return;                                                                                                \
+    }                                                                                                          \
+    if (state == W_CREATION_ERROR) return;                                                                     \
+    {                                                                                                          \
+        const int rc = CALL;                                                                                   \
+        if (rc != PDWT_OK) {                                                                                   \
+            report("Wavelets::" NAME "()", rc);                                                                \
+            state = W_THRESHOLD_ERROR;                                                                         \
+        }                                                                                                      \
+    }
+void Wavelets::hard_threshold(DTYPE beta, int do_thresh_appcoeffs, int normalize)
 {
-    printf("ERROR: Wavelets::%s is not part of this build (hot path only: forward, inverse, soft_threshold, norm1)\n", what);
+    PDWT_THRESH_METHOD("hard_threshold", SFX(pdwt_hard_thresh)(d_coeffs, beta, to_pdwt(winfos), do_thresh_appcoeffs, normalize))
 }
-void Wavelets::hard_threshold(DTYPE, int, int) { not_built("hard_threshold()"); state = (state == W_INVERSE) ? state : W_THRESHOLD_ERROR; }
-void Wavelets::group_soft_threshold(DTYPE, int, int) { not_built("group_soft_threshold()"); state = (state == W_INVERSE) ? state : W_THRESHOLD_ERROR; }
-void Wavelets::shrink(DTYPE, int) { not_built("shrink()"); state = (state == W_INVERSE) ? state : W_THRESHOLD_ERROR; }
-void Wavelets::proj_linf(DTYPE, int) { not_built("proj_linf()"); state = (state == W_INVERSE) ? state : W_THRESHOLD_ERROR; }
-void Wavelets::circshift(int, int, int) { not_built("circshift()"); }
-DTYPE Wavelets::norm2sq() { not_built("norm2sq()"); return (DTYPE)-1; }
-int Wavelets::set_filters_forward(char*, uint, DTYPE*, DTYPE*, DTYPE*, DTYPE*) { not_built("set_filters_forward()"); return -3; }
-int Wavelets::set_filters_inverse(DTYPE*, DTYPE*, DTYPE*, DTYPE*) { not_built("set_filters_inverse()"); return -3; }
-int Wavelets::add_wavelet(Wavelets, DTYPE) { not_built("add_wavelet()"); return -5; }
+void Wavelets::group_soft_threshold(DTYPE beta, int do_thresh_appcoeffs, int normalize)
+{
+    PDWT_THRESH_METHOD("group_soft_threshold", SFX(pdwt_group_soft_thresh)(d_coeffs, beta, to_pdwt(winfos), do_thresh_appcoeffs, normalize))
+}
+void Wavelets::shrink(DTYPE beta, int do_thresh_appcoeffs)
+{
+    PDWT_THRESH_METHOD("shrink", SFX(pdwt_shrink)(d_coeffs, beta, to_pdwt(winfos), do_thresh_appcoeffs))
+}
+void Wavelets::proj_linf(DTYPE beta, int do_thresh_appcoeffs)
+{
+    PDWT_THRESH_METHOD("proj_linf", SFX(pdwt_proj_linf)(d_coeffs, beta, to_pdwt(winfos), do_thresh_appcoeffs))
+}
+
+// src/wt.cu:364-366: if inplace = 1 the result is in d_image, otherwise in d_tmp
+void Wavelets::circshift(int sr, int sc, int inplace)
+{
+    if (state == W_CREATION_ERROR || !d_image || !d_tmp) return;
+    const int rc = SFX(pdwt_circshift)(d_image, d_tmp, to_pdwt(winfos), sr, sc, inplace);
+    if (rc != PDWT_OK) report("Wavelets::circshift()", rc);
+}
+
+DTYPE Wavelets::norm2sq()
+{
+    if (state == W_CREATION_ERROR) return 0;
+    DTYPE res = 0;
+    const int rc = SFX(pdwt_norm2sq)(d_coeffs, to_pdwt(winfos), &res);
+    if (rc != PDWT_OK) report("Wavelets::norm2sq()", rc);
+    return res;
+}
+
+// Custom filter banks (src/wt.cu:560-602).  The taps become per-instance state (the reference uploads them to the
+// process-global constant memory, SURVEY B-1).  Only the separable path exists in this build: filter3/filter4 of
+// the non-separable form are rejected like the reference rejects their absence (-2).
+int Wavelets::set_filters_forward(char* filtername, uint len, DTYPE* filter1, DTYPE* filter2, DTYPE* filter3, DTYPE* filter4)
+{
+    (void)filter3;
+    (void)filter4;
+    if (len > PDWT_MAX_FILTER_WIDTH) {
+        printf("ERROR: Wavelets.set_filters_forward(): filter length (%d) exceeds the maximum size (%d)\n", (int)len, PDWT_MAX_FILTER_WIDTH);
+        return -1;
+    }
+    if (!do_separable) {
+        puts("ERROR: Wavelets.set_filters_forward(): non-separable filtering is not part of this build");
+        return -2;
+    }
+    if (!filter1 || !filter2 || len < 2) return -2;
+    if (!filters_) {
+        filters_ = calloc(1, sizeof(filters_t));
+        if (!filters_) return -3;
+    }
+    filters_t* f = static_cast<filters_t*>(filters_);
+    for (unsigned i = 0; i < PDWT_MAX_FILTER_WIDTH; i++) {
+        f->L[i] = (i < len) ? filter1[i] : (DTYPE)0;
+        f->H[i] = (i < len) ? filter2[i] : (DTYPE)0;
+    }
+    f->hlen = (int)len;
+    winfos.hlen = (int)len;
+    if (filtername) {
+        strncpy(wname, filtername, sizeof(wname) - 1);
+        wname[sizeof(wname) - 1] = 0;
+    }
+    return 0;
+}
+
+// the inverse filters are assumed to have the length given to set_filters_forward() (src/wt.cu:584-602)
+int Wavelets::set_filters_inverse(DTYPE* filter1, DTYPE* filter2, DTYPE* filter3, DTYPE* filter4)
+{
+    (void)filter3;
+    (void)filter4;
+    if (!do_separable) {
+        puts("ERROR: Wavelets.set_filters_inverse(): non-separable filtering is not part of this build");
+        return -2;
+    }
+    if (!filter1 || !filter2 || !filters_) return -2;
+    filters_t* f = static_cast<filters_t*>(filters_);
+    const int len = winfos.hlen;
+    for (int i = 0; i < PDWT_MAX_FILTER_WIDTH; i++) {
+        f->IL[i] = (i < len) ? filter1[i] : (DTYPE)0;
+        f->IH[i] = (i < len) ? filter2[i] : (DTYPE)0;
+    }
+    return 0;
+}
+
+// In-place addition of wavelet coefficients: this += alpha * W (src/wt.cu:624-657); the operand comes by value
+// (deep copy) as in the reference header.
+int Wavelets::add_wavelet(Wavelets W, DTYPE alpha)
+{
+    if ((winfos.nlevels != W.winfos.nlevels) || (strcasecmp(wname, W.wname))) {
+        puts("ERROR: add_wavelet(): right operand is not the same transform (wname, level)");
+        return -1;
+    }
+    if (state == W_INVERSE || W.state == W_INVERSE) {
+        puts("WARNING: add_wavelet(): this operation makes no sense when wavelet has just been inverted");
+        return 1;
+    }
+    if (winfos.Nr != W.winfos.Nr || winfos.Nc != W.winfos.Nc || winfos.ndims != W.winfos.ndims) {
+        puts("ERROR: add_wavelet(): operands do not have the same geometry");
+        return -2;
+    }
+    if ((winfos.do_swt) ^ (W.winfos.do_swt)) {
+        puts("ERROR: add_wavelet(): operands should both use SWT or DWT");
+        return -3;
+    }
+    if ((do_cycle_spinning && W.do_cycle_spinning) && ((current_shift_r != W.current_shift_r) || (current_shift_c != W.current_shift_c))) {
+        puts("ERROR: add_wavelet(): operands do not have the same current shift");
+        return -4;
+    }
+    if (state == W_CREATION_ERROR || W.state == W_CREATION_ERROR || !d_coeffs || !W.d_coeffs) return -5;
+    const int rc = SFX(pdwt_add_coeffs)(d_coeffs, W.d_coeffs, to_pdwt(winfos), alpha);
+    if (rc != PDWT_OK) {
+        report("Wavelets::add_wavelet()", rc);
+        return -5;
+    }
+    pdwt_sync();  // W (a by-value copy) is destroyed on return: its bands must outlive the launch
+    return 0;
+}
 
 // ---- data movement ---------------------------------------------------------------------------------
 int Wavelets::get_image(DTYPE* res)

@@ -23,6 +23,16 @@ void pdwt_wavelets_forward(void* h) { W(h)->forward(); }
 void pdwt_wavelets_inverse(void* h) { W(h)->inverse(); }
 void pdwt_wavelets_soft_threshold(void* h, DTYPE beta, int do_thresh_appcoeffs, int normalize) { W(h)->soft_threshold(beta, do_thresh_appcoeffs, normalize); }
 DTYPE pdwt_wavelets_norm1(void* h) { return W(h)->norm1(); }
+void pdwt_wavelets_hard_threshold(void* h, DTYPE beta, int do_thresh_appcoeffs, int normalize) { W(h)->hard_threshold(beta, do_thresh_appcoeffs, normalize); }
+void pdwt_wavelets_group_soft_threshold(void* h, DTYPE beta, int do_thresh_appcoeffs, int normalize) { W(h)->group_soft_threshold(beta, do_thresh_appcoeffs, normalize); }
+void pdwt_wavelets_shrink(void* h, DTYPE beta, int do_thresh_appcoeffs) { W(h)->shrink(beta, do_thresh_appcoeffs); }
+void pdwt_wavelets_proj_linf(void* h, DTYPE beta, int do_thresh_appcoeffs) { W(h)->proj_linf(beta, do_thresh_appcoeffs); }
+void pdwt_wavelets_circshift(void* h, int sr, int sc, int inplace) { W(h)->circshift(sr, sc, inplace); }
+DTYPE pdwt_wavelets_norm2sq(void* h) { return W(h)->norm2sq(); }
+int pdwt_wavelets_set_filters_forward(void* h, char* name, unsigned len, DTYPE* f1, DTYPE* f2) { return W(h)->set_filters_forward(name, len, f1, f2); }
+int pdwt_wavelets_set_filters_inverse(void* h, DTYPE* f1, DTYPE* f2) { return W(h)->set_filters_inverse(f1, f2); }
+int pdwt_wavelets_add_wavelet(void* h, void* other, DTYPE alpha) { return W(h)->add_wavelet(*W(other), alpha); }
+void pdwt_wavelets_shifts(void* h, int* sr, int* sc) { *sr = W(h)->current_shift_r; *sc = W(h)->current_shift_c; }
 int pdwt_wavelets_get_image(void* h, DTYPE* out) { return W(h)->get_image(out); }
 void pdwt_wavelets_set_image(void* h, DTYPE* img, int mem_is_on_device) { W(h)->set_image(img, mem_is_on_device); }
 int pdwt_wavelets_get_coeff(void* h, DTYPE* out, int num) { return W(h)->get_coeff(out, num); }

@@ -99,6 +99,55 @@ class Wavelets:
     def norm1(self):
         return self.dtype.type(self._L.pdwt_wavelets_norm1(self._h))
 
+    def hard_threshold(self, beta, do_thresh_appcoeffs=0, normalize=0):
+        self._L.pdwt_wavelets_hard_threshold(self._h, self._ct(beta), int(do_thresh_appcoeffs), int(normalize))
+
+    def group_soft_threshold(self, beta, do_thresh_appcoeffs=0, normalize=0):
+        self._L.pdwt_wavelets_group_soft_threshold(self._h, self._ct(beta), int(do_thresh_appcoeffs), int(normalize))
+
+    def shrink(self, beta, do_thresh_appcoeffs=1):
+        self._L.pdwt_wavelets_shrink(self._h, self._ct(beta), int(do_thresh_appcoeffs))
+
+    def proj_linf(self, beta, do_thresh_appcoeffs=1):
+        self._L.pdwt_wavelets_proj_linf(self._h, self._ct(beta), int(do_thresh_appcoeffs))
+
+    def circshift(self, sr, sc, inplace=1):
+        self._L.pdwt_wavelets_circshift(self._h, int(sr), int(sc), int(inplace))
+
+    def norm2sq(self):
+        return self.dtype.type(self._L.pdwt_wavelets_norm2sq(self._h))
+
+    def set_filters_forward(self, name, lo, hi):
+        """Custom analysis bank (reference Wavelets::set_filters_forward, separable form)."""
+        a = np.ascontiguousarray(lo, dtype=self.dtype)
+        b = np.ascontiguousarray(hi, dtype=self.dtype)
+        assert a.size == b.size
+        return self._L.pdwt_wavelets_set_filters_forward(self._h, name.encode(), a.size, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+
+    def set_filters_inverse(self, lo, hi):
+        a = np.ascontiguousarray(lo, dtype=self.dtype)
+        b = np.ascontiguousarray(hi, dtype=self.dtype)
+        assert a.size == b.size == self.info.hlen
+        return self._L.pdwt_wavelets_set_filters_inverse(self._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+
+    def add_wavelet(self, other, alpha=1.0):
+        """self += alpha * other on every band (reference Wavelets::add_wavelet)."""
+        return self._L.pdwt_wavelets_add_wavelet(self._h, other._h, self._ct(alpha))
+
+    @property
+    def current_shift(self):
+        r, c = C.c_int(), C.c_int()
+        self._L.pdwt_wavelets_shifts(self._h, C.byref(r), C.byref(c))
+        return r.value, c.value
+
+    def get_tmp(self):
+        """First Nr*Nc elements of d_tmp (where circshift(..., inplace=0) leaves its result)."""
+        out = np.empty(self.shape, dtype=self.dtype)
+        rc = N.hip().pdwt_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self._L.pdwt_wavelets_tmp_int_ptr(self._h)), out.nbytes)
+        if rc != 0:
+            raise RuntimeError("get_tmp failed")
+        return out
+
     def norm1_f64(self):
         """Sum of |c| over all bands, in double (pdwt_norm1_as_double_*): shard-combinable."""
         out = C.c_double()

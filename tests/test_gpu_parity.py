@@ -392,3 +392,174 @@ def test_cascade_equals_per_level(wname, monkeypatch):
         O.forward()
         for a, b in zip(res[0][0], O.coeffs):
             assert band_err(a, b) <= TOL[np.dtype(np.float32)]
+
+
+# ---- remaining coefficient utilities, custom filters, cycle spinning -------------------------
+UTIL_CASES = [
+    # (shape, wname, levels, kwargs, dtype)
+    ((96, 160), "db4", 3, dict(), np.float32),
+    ((75, 131), "sym4", 2, dict(), np.float64),          # odd sizes
+    ((6, 300), "db3", 3, dict(ndim=1), np.float32),      # batched 1-D
+    ((64, 80), "db2", 2, dict(do_swt=1), np.float64),    # SWT: every band full size
+    ((128, 128), "haar", 2, dict(), np.float32),
+]
+UTIL_OPS = {
+    "hard": lambda W, b: W.hard_threshold(b, 0, 0),
+    "hard_app_norm": lambda W, b: W.hard_threshold(b, 1, 1),
+    "soft_app_norm": lambda W, b: W.soft_threshold(b, 1, 1),
+    "proj": lambda W, b: W.proj_linf(b),
+    "proj_noapp": lambda W, b: W.proj_linf(b, 0),
+    "shrink": lambda W, b: W.shrink(b),
+    "group": lambda W, b: W.group_soft_threshold(b, 0, 0),
+    "group_app_norm": lambda W, b: W.group_soft_threshold(b, 1, 1),
+}
+
+
+@pytest.mark.parametrize("op", sorted(UTIL_OPS))
+@pytest.mark.parametrize("case", range(len(UTIL_CASES)))
+def test_coefficient_utilities_vs_oracle(case, op):
+    shape, wname, levels, kw, dt = UTIL_CASES[case]
+    x = np.random.RandomState(40 + case).uniform(-1, 1, shape).astype(dt) * 50
+    W, O = _pair(x, wname, levels, **kw)
+    W.forward()
+    O.forward()
+    # the same coefficients on both sides, so that a threshold never falls between two slightly different values
+    for k, b in enumerate(W.coeffs):
+        O.set_coeff(b, k)
+    beta = float(np.median(np.abs(W.get_coeff(W.nbands - 1)))) * 1.5
+    UTIL_OPS[op](W, beta)
+    UTIL_OPS[op](O, beta)
+    for k, (g, o) in enumerate(zip(W.coeffs, O.coeffs)):
+        if op.startswith("group"):
+            assert band_err(g, o) <= 4 * TOL[np.dtype(dt)], (op, k)  # sqrt + divide: a few ulp
+        else:
+            assert np.array_equal(g, o), (op, k)  # select / min / one multiply: bit-exact
+    n2w, n2o = float(W.norm2sq()), float(O.norm2sq())
+    assert abs(n2w - n2o) <= (2e-6 if dt == np.float32 else 1e-12) * abs(n2o)
+    n1w, n1o = float(W.norm1()), float(O.norm1())
+    assert abs(n1w - n1o) <= (2e-6 if dt == np.float32 else 1e-12) * abs(n1o)
+
+
+def test_utilities_vs_pywt_golden():
+    d = load_golden("utils64x96_db4_L3")
+    beta = float(d["beta"])
+    for dt in (np.float32, np.float64):
+        for prefix, call in (("hard", lambda W: W.hard_threshold(beta)), ("proj", lambda W: W.proj_linf(beta)), ("shrink", lambda W: W.shrink(beta)),
+                             ("group", lambda W: W.group_soft_threshold(beta)), ("softnorm", lambda W: W.soft_threshold(beta, 0, 1))):
+            W = pdwt_amd.Wavelets(d["input"].astype(dt), d["wname"], d["levels"])
+            W.forward()
+            if prefix == "hard":
+                assert abs(float(W.norm2sq()) - float(d["norm2sq"])) <= (1e-5 if dt == np.float32 else 1e-10) * float(d["norm2sq"])
+            call(W)
+            tol = 2e-5 if dt == np.float32 else 1e-9
+            for k in range(d["nbands"]):
+                e = d["%s%d" % (prefix, k)]
+                g = W.get_coeff(k)
+                if prefix in ("hard", "softnorm") and dt == np.float32:
+                    # a float32 coefficient within rounding of the threshold may fall on the other side: compare away from it
+                    far = np.abs(np.abs(d["band%d" % k]) - beta / (np.sqrt(2.0) ** ((k + 2) // 3) if prefix == "softnorm" else 1.0)) > 1e-2
+                    assert np.abs(g - e)[far].max() <= tol * max(np.abs(e).max(), 1.0), (prefix, k)
+                else:
+                    assert band_err(g, e) <= tol, (prefix, k, band_err(g, e))
+
+
+def test_add_wavelet_and_error_codes():
+    rs = np.random.RandomState(51)
+    x, y = rs.randn(64, 96).astype(np.float32), rs.randn(64, 96).astype(np.float32)
+    A, B = pdwt_amd.Wavelets(x, "db4", 2), pdwt_amd.Wavelets(y, "db4", 2)
+    A.forward()
+    B.forward()
+    ca, cb = A.coeffs, B.coeffs
+    assert A.add_wavelet(B, 0.25) == 0
+    for k, g in enumerate(A.coeffs):
+        assert np.array_equal(g, np.float32(0.25) * cb[k] + ca[k]) or band_err(g, ca[k] + 0.25 * cb[k]) <= 1e-6
+    assert np.array_equal(B.coeffs[3], cb[3])  # the operand is untouched (it is passed by value)
+    C_ = pdwt_amd.Wavelets(x, "db3", 2)
+    C_.forward()
+    assert A.add_wavelet(C_) == -1          # other transform
+    D_ = pdwt_amd.Wavelets(x[:, :64].copy(), "db4", 2)
+    D_.forward()
+    assert A.add_wavelet(D_) == -2          # other geometry
+    E_ = pdwt_amd.Wavelets(x, "db4", 2, do_swt=1)
+    E_.forward()
+    assert A.add_wavelet(E_) == -3          # DWT vs SWT
+    B.inverse()
+    assert A.add_wavelet(B) == 1            # makes no sense after inverse
+    # linearity through the inverse: W(x) + 0.25 W(y) reconstructs x + 0.25 y
+    A.inverse()
+    assert band_err(A.get_image(), x + 0.25 * y) <= 1e-5
+
+
+def test_threshold_refused_after_inverse():
+    x = np.random.RandomState(52).randn(64, 64).astype(np.float32)
+    W = pdwt_amd.Wavelets(x, "db2", 2)
+    W.forward()
+    W.inverse()
+    for f in (lambda: W.hard_threshold(1e9), lambda: W.group_soft_threshold(1e9), lambda: W.shrink(1e9), lambda: W.proj_linf(0.0)):
+        f()
+    assert W.state == pdwt_amd.W_INVERSE
+    assert band_err(W.get_image(), x) <= 1e-5
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_custom_filters_vs_pywt_golden(dt):
+    d = load_golden("custom80x64_bior33_L2")
+    W = pdwt_amd.Wavelets(d["input"].astype(dt), "haar", d["levels"])
+    assert W.set_filters_forward("custom_bior33", d["dec_lo"], d["dec_hi"]) == 0
+    assert W.set_filters_inverse(d["rec_lo"], d["rec_hi"]) == 0
+    assert W.info.hlen == 8
+    W.forward()
+    for k in range(d["nbands"]):
+        assert band_err(W.get_coeff(k), d["band%d" % k]) <= TOL[np.dtype(dt)], k
+    W.inverse()
+    assert band_err(W.get_image(), d["recon"]) <= TOL[np.dtype(dt)]
+    assert W.set_filters_forward("too_long", np.zeros(41), np.zeros(41)) == -1
+
+
+def test_custom_odd_length_filters_vs_oracle():
+    """Odd filter lengths take the `hlen & 1` branches (src/separable.cu:98-102); only custom banks reach them."""
+    rs = np.random.RandomState(53)
+    lo, hi = rs.randn(5), rs.randn(5)
+    for shape, kw in (((40, 56), dict()), ((3, 90), dict(ndim=1)), ((32, 48), dict(do_swt=1))):
+        x = rs.randn(*shape)
+        W, O = _pair(x, "db2", 2, **kw)
+        for Z in (W, O):
+            assert Z.set_filters_forward("odd5", lo, hi) == 0
+            assert Z.set_filters_inverse(lo[::-1], hi[::-1]) == 0
+            Z.forward()
+        for k, (g, o) in enumerate(zip(W.coeffs, O.coeffs)):
+            assert band_err(g, o) <= 1e-10, (shape, k)
+        W.inverse()
+        O.inverse()
+        assert band_err(W.get_image(), O.get_image()) <= 1e-10
+
+
+def test_circshift_and_cycle_spinning():
+    d = load_golden("shift48x72_db3_L2")
+    sr, sc = int(d["sr"]), int(d["sc"])
+    for dt in (np.float32, np.float64):
+        x = d["input"].astype(dt)
+        W = pdwt_amd.Wavelets(x, d["wname"], d["levels"])
+        W.circshift(3, -4, 0)                       # result in d_tmp, image untouched
+        assert np.array_equal(W.get_image(), x)
+        assert np.array_equal(W.get_tmp(), np.roll(x, (3, -4), axis=(0, 1)))
+        W.circshift(sr, sc, 1)
+        assert np.array_equal(W.get_image(), d["shifted"].astype(dt))
+        W.forward()
+        for k in range(d["nbands"]):
+            assert band_err(W.get_coeff(k), d["band%d" % k]) <= TOL[np.dtype(dt)], k
+        W.inverse()
+        W.circshift(-sr, -sc, 1)
+        assert band_err(W.get_image(), x) <= TOL[np.dtype(dt)]
+    # do_cycle_spinning=1: forward() shifts by a random (current_shift_r, current_shift_c), inverse() shifts back
+    x = d["input"].astype(np.float64)
+    W = pdwt_amd.Wavelets(x, "db3", 2, do_cycle_spinning=1)
+    W.forward()
+    r, c = W.current_shift
+    assert 0 <= r < 48 and 0 <= c < 72
+    O = orc.OracleWavelets(np.roll(x, (r, c), axis=(0, 1)), "db3", 2)
+    O.forward()
+    for k, (g, o) in enumerate(zip(W.coeffs, O.coeffs)):
+        assert band_err(g, o) <= 1e-10, k
+    W.inverse()
+    assert band_err(W.get_image(), x) <= 1e-10
