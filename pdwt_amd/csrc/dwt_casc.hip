@@ -56,8 +56,8 @@ constexpr int casc_fwd_after(int p)
     return n;
 }
 
-// PF = prefetch distance in bodies of HLEN input rows (1: HLEN KiB in flight per wave, 2: 2*HLEN KiB)
-template <int HLEN, int PF>
+// NV = row registers = input rows (KiB) in flight per wave = prefetch distance (HLEN/2, HLEN or 2*HLEN)
+template <int HLEN, int NV>
 __global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in, CascBands b, int Nr, int Nc, int VL,
                                                      float* __restrict__ trash, CascMap cm, TapsLH f)
 {
@@ -138,7 +138,6 @@ __global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in
     };
 
     // ring prologue rows 0..HLEN-3 and the first body's rows, issued together
-    constexpr int NV = PF * HLEN;   // row registers = input rows in flight
     constexpr int DIST = NV / 2;    // prefetch distance in A1 rows
     static_assert(casc_fwd_after<DIST>(1) <= 63, "vmcnt is a 6-bit counter");
     v4f v[NV];
@@ -257,13 +256,16 @@ struct CascInvBands {
     const float *A2, *H2, *V2, *D2, *H1, *V1, *D1;
 };
 
-template <int HLEN>
+// PFD = prefetch distance in steps (row registers are re-issued for the step PFD steps ahead; H2 % PFD == 0)
+template <int HLEN, int PFD>
 __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __restrict__ out, int Nr, int Nc, int VL,
                                                      float* __restrict__ trash, CascMap cm, Taps2<float> f)
 {
     using G = CascInvGeom<HLEN>;
     constexpr int H2 = G::H2, C = G::C, SHIFT = G::SHIFT, NB1 = G::NB1, NB2 = G::NB2, NBT = G::NBT, WIN1 = G::WIN1, WIN2 = G::WIN2;
-    static_assert(G::VM_SB - 3 <= 63, "vmcnt is a 6-bit counter");
+    constexpr int VM_PF = PFD * (4 + 2 * (3 + 2));  // VMEM instructions per prefetch period
+    static_assert(VM_PF - 3 <= 63, "vmcnt is a 6-bit counter");
+    static_assert(H2 % PFD == 0 || PFD % H2 == 0, "register slots must be compile-time constants");
     const int lane = threadIdx.x & 63;
     const int xcd = blockIdx.x & 7;
     // the wave index is uniform, but only readfirstlane tells the compiler: everything derived from it (rows, row
@@ -306,8 +308,8 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
     v2f ra[H2], rh[H2], rv[H2], rd[H2];   // level l ring: the lane's two columns of each band
 #pragma unroll
     for (int k = 0; k < H2; k++) ra[k] = rh[k] = rv[k] = rd[k] = v2f{0.f, 0.f};
-    float q2[H2][4];                      // row registers in flight, level l+1 (one per step of a super-body)
-    v2f q1[HLEN][3];                      // row registers in flight, level l (two per step)
+    float q2[PFD][4];                     // row registers in flight, level l+1 (one per step of a prefetch period)
+    v2f q1[2 * PFD][3];                   // row registers in flight, level l (two per step)
     {
 #pragma unroll
         for (int r = 0; r < H2 - 1; r++) {
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
         }
         r2av[H2 - 1] = r2hd[H2 - 1] = v2f{0.f, 0.f};
 #pragma unroll
-        for (int p = 0; p < H2; p++) {
+        for (int p = 0; p < PFD; p++) {
             const size_t o = off2(H2 - 1 + p);
             q2[p][0] = pA2[o];
             q2[p][1] = pH2[o];
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
             q2[p][3] = pD2[o];
         }
 #pragma unroll
-        for (int q = 0; q < HLEN; q++) {
+        for (int q = 0; q < 2 * PFD; q++) {
             const size_t o = off1(q);
             q1[q][0] = *reinterpret_cast<const v2f*>(pH1 + o);
             q1[q][1] = *reinterpret_cast<const v2f*>(pV1 + o);
@@ -446,20 +448,21 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
         a1 = o2[1];
     };
 
-    constexpr int kWait2 = G::VM_SB - 4, kWait1 = G::VM_SB - 3;
+    constexpr int kWait2 = VM_PF - 4, kWait1 = VM_PF - 3;
     auto step = [&](auto Pp, int sb) {
         constexpr int p = decltype(Pp)::value;
         const int s = sb * H2 + p;
         // ---- level l+1: coefficient row r2 = H2-1+s completes the window of step s ----
-        asm_wait4<kWait2>(q2[p][0], q2[p][1], q2[p][2], q2[p][3]);
-        r2av[(H2 - 1 + p) % H2] = v2f{q2[p][0], q2[p][2]};
-        r2hd[(H2 - 1 + p) % H2] = v2f{q2[p][1], q2[p][3]};
+        constexpr int pr = p % PFD;  // register slot of this step
+        asm_wait4<kWait2>(q2[pr][0], q2[pr][1], q2[pr][2], q2[pr][3]);
+        r2av[(H2 - 1 + p) % H2] = v2f{asm_copy(q2[pr][0]), asm_copy(q2[pr][2])};
+        r2hd[(H2 - 1 + p) % H2] = v2f{asm_copy(q2[pr][1]), asm_copy(q2[pr][3])};
         {
-            const size_t o = off2(min(2 * H2 - 1 + s, H2 - 2 + nsteps));  // the row this step needs one super-body ahead (clamped to the last one)
-            asm_load_s(q2[p][0], b.A2 + o, voff2);
-            asm_load_s(q2[p][1], b.H2 + o, voff2);
-            asm_load_s(q2[p][2], b.V2 + o, voff2);
-            asm_load_s(q2[p][3], b.D2 + o, voff2);
+            const size_t o = off2(min(H2 - 1 + s + PFD, H2 - 2 + nsteps));  // the row needed PFD steps ahead (clamped to the last one)
+            asm_load_s(q2[pr][0], b.A2 + o, voff2);
+            asm_load_s(q2[pr][1], b.H2 + o, voff2);
+            asm_load_s(q2[pr][2], b.V2 + o, voff2);
+            asm_load_s(q2[pr][3], b.D2 + o, voff2);
         }
         static_for<2>([&](auto I) {
             constexpr int idx = decltype(I)::value;  // 0: tap parity 1 (A_l row 2P-SHIFT), 1: parity 0 (the next row)
@@ -468,16 +471,17 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
             synth2(std::integral_constant<int, p % H2>{}, std::integral_constant<int, 1 - idx>{}, a0, a1);
             // ---- level l: stream row r1 enters the ring with its H,V,D row ----
             const int r1 = 2 * s + idx;
-            asm_wait3<kWait1>(q1[q][0], q1[q][1], q1[q][2]);
+            constexpr int qr = q % (2 * PFD);  // register slot of this row
+            asm_wait3<kWait1>(q1[qr][0], q1[qr][1], q1[qr][2]);
             ra[q % H2] = v2f{a0, a1};
-            rh[q % H2] = q1[q][0];
-            rv[q % H2] = q1[q][1];
-            rd[q % H2] = q1[q][2];
+            rh[q % H2] = asm_copy(q1[qr][0]);
+            rv[q % H2] = asm_copy(q1[qr][1]);
+            rd[q % H2] = asm_copy(q1[qr][2]);
             {
-                const size_t o = off1(min(r1 + HLEN, 2 * nsteps - 1));
-                asm_load_s(q1[q][0], b.H1 + o, voff1);
-                asm_load_s(q1[q][1], b.V1 + o, voff1);
-                asm_load_s(q1[q][2], b.D1 + o, voff1);
+                const size_t o = off1(min(r1 + 2 * PFD, 2 * nsteps - 1));
+                asm_load_s(q1[qr][0], b.H1 + o, voff1);
+                asm_load_s(q1[qr][1], b.V1 + o, voff1);
+                asm_load_s(q1[qr][2], b.D1 + o, voff1);
             }
             const int g1 = 2 * (r1 - (H2 - 1)) - SHIFT;
             emit(std::integral_constant<int, (q + 1) % H2>{}, std::integral_constant<int, 1>{}, g1);
@@ -485,14 +489,14 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
         });
     };
 
-    static_for<H2>([&](auto K) {
+    static_for<PFD>([&](auto K) {
         constexpr int k = decltype(K)::value;
         asm_drain1(q2[k][0]);
         asm_drain1(q2[k][1]);
         asm_drain1(q2[k][2]);
         asm_drain1(q2[k][3]);
     });
-    static_for<HLEN>([&](auto K) {
+    static_for<2 * PFD>([&](auto K) {
         constexpr int k = decltype(K)::value;
         asm_drain1(q1[k][0]);
         asm_drain1(q1[k][1]);
@@ -508,14 +512,14 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
         });
         if (fin) break;
     }
-    static_for<H2>([&](auto K) {
+    static_for<PFD>([&](auto K) {
         constexpr int k = decltype(K)::value;
         asm_drain1(q2[k][0]);
         asm_drain1(q2[k][1]);
         asm_drain1(q2[k][2]);
         asm_drain1(q2[k][3]);
     });
-    static_for<HLEN>([&](auto K) {
+    static_for<2 * PFD>([&](auto K) {
         constexpr int k = decltype(K)::value;
         asm_drain1(q1[k][0]);
         asm_drain1(q1[k][1]);
@@ -553,8 +557,15 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
     const CascMap cm = {cpx, strips};
     const dim3 grid((unsigned)(8 * idiv_up(cpx * strips, 4)));
     KTimer kt(K_FWD2D_CASC);
-    // (PF = 2 measured no faster on MI355X: 28.5 vs 27.2 us at 4096^2 db4 -- the kernel is not latency-bound)
-    hipLaunchKernelGGL((k_fwd2d_casc<HLEN, 1>), grid, dim3(256), 0, stream(), in, b, nr, nc, VL, trash, cm, f);
+    // row registers in flight (= prefetch distance): HLEN/2 measured best (26.2 us vs 26.8 @HLEN, 28.5 @2*HLEN for 4096^2 db4);
+    // a shorter pipeline fills and drains faster, and every wave fills and drains at the same time
+    const int nv = env_int("PDWT_CASC_NV", HLEN % 4 == 0 ? HLEN / 2 : HLEN);
+    if (nv == 2)
+        hipLaunchKernelGGL((k_fwd2d_casc<HLEN, 2>), grid, dim3(256), 0, stream(), in, b, nr, nc, VL, trash, cm, f);
+    else if (nv < HLEN && HLEN % 4 == 0)
+        hipLaunchKernelGGL((k_fwd2d_casc<HLEN, (HLEN % 4 == 0 ? HLEN / 2 : HLEN)>), grid, dim3(256), 0, stream(), in, b, nr, nc, VL, trash, cm, f);
+    else
+        hipLaunchKernelGGL((k_fwd2d_casc<HLEN, HLEN>), grid, dim3(256), 0, stream(), in, b, nr, nc, VL, trash, cm, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -585,13 +596,21 @@ static int launch_inv_casc(const CascInvBands& b, float* out, float* trash, int 
     const int nc1 = nc / 2;
     const int strips = idiv_up(nc1, MAXVL * 2);
     const int VL = idiv_up(nc1 / 2, strips);
-    int cpx = env_int("PDWT_CASC_IWAVES", 1024) / (8 * strips);
+    int cpx = env_int("PDWT_CASC_IWAVES", 2048) / (8 * strips);
     if (cpx > nr / 2 / 8 / 8) cpx = nr / 2 / 8 / 8;  // at least 8 level-l coefficient rows per chunk
     if (cpx < 1) cpx = 1;
     const CascMap cm = {cpx, strips};
     const dim3 grid((unsigned)(8 * idiv_up(cpx * strips, 4)));
     KTimer kt(K_INV2D_CASC);
-    hipLaunchKernelGGL(k_inv2d_casc<HLEN>, grid, dim3(256), 0, stream(), b, out, nr, nc, VL, trash, cm, f);
+    constexpr int H2 = HLEN / 2;
+    // prefetch distance in steps: 1 measured best (28.2 us vs 29.5 @2, 31.5 @H2 for 4096^2 db4, 2048 waves)
+    const int pfd = env_int("PDWT_CASC_IPFD", 1);
+    if (pfd == 1)
+        hipLaunchKernelGGL((k_inv2d_casc<HLEN, 1>), grid, dim3(256), 0, stream(), b, out, nr, nc, VL, trash, cm, f);
+    else if (pfd < H2 && H2 % 2 == 0)
+        hipLaunchKernelGGL((k_inv2d_casc<HLEN, (H2 % 2 == 0 ? H2 / 2 : H2)>), grid, dim3(256), 0, stream(), b, out, nr, nc, VL, trash, cm, f);
+    else
+        hipLaunchKernelGGL((k_inv2d_casc<HLEN, H2>), grid, dim3(256), 0, stream(), b, out, nr, nc, VL, trash, cm, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }

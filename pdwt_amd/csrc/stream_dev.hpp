@@ -91,9 +91,12 @@ __device__ __forceinline__ void vstore(float* p, const float (&a)[1]) { *p = a[0
 // Memory instructions retire in issue order, so "at most N outstanding" means the load has landed while the
 // N younger loads/stores stay in flight.  Rules that keep the count exact: every lane-predicated store goes
 // to a trash slot instead of being branched around; the loop is entered and left through vmcnt(0).
-__device__ __forceinline__ void asm_load(v4f& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
-__device__ __forceinline__ void asm_load(v2f& d, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
-__device__ __forceinline__ void asm_load(float& d, const float* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+// The destination is a TIED operand ("+v"): the in-flight value keeps the physical register of the value it
+// replaces, so the compiler never has to copy a register whose load has not landed yet (it believes the asm
+// defines it at once; a v_mov of such a register -- e.g. a phi copy at a loop back-edge -- would read stale data).
+__device__ __forceinline__ void asm_load(v4f& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void asm_load(v2f& d, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void asm_load(float& d, const float* p) { asm volatile("global_load_dword %0, %1, off" : "+v"(d) : "v"(p) : "memory"); }
 __device__ __forceinline__ void asm_store(float* p, v2f d) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(d) : "memory"); }
 __device__ __forceinline__ void asm_store(float* p, float d) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(d) : "memory"); }
 __device__ __forceinline__ void asm_store(float* p, v4f d) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(d) : "memory"); }
@@ -104,15 +107,15 @@ __device__ __forceinline__ void asm_store(float* p, v4f d) { asm volatile("globa
 typedef unsigned long long lanemask_t;
 __device__ __forceinline__ void asm_load_s(v4f& d, const float* sbase, unsigned voff)
 {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void asm_load_s(v2f& d, const float* sbase, unsigned voff)
 {
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void asm_load_s(float& d, const float* sbase, unsigned voff)
 {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("global_load_dword %0, %1, %2" : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void asm_store_sm(float* sbase, unsigned voff, v2f d, lanemask_t mask)
 {
@@ -131,6 +134,20 @@ __device__ __forceinline__ void asm_store_sm(float* sbase, unsigned voff, v4f d,
     lanemask_t saved;
     asm volatile("s_and_saveexec_b64 %0, %4\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_nop 1\n\ts_mov_b64 exec, %0"
                  : "=&s"(saved) : "v"(voff), "v"(d), "s"(sbase), "s"(mask) : "memory", "scc");
+}
+// Opaque register copies out of a load register.  A plain C++ copy may be coalesced with its source; the tied
+// load that follows would then be given a fresh register and the loop back-edge a v_mov of the in-flight one.
+__device__ __forceinline__ float asm_copy(const float& src)
+{
+    float d;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(src));
+    return d;
+}
+__device__ __forceinline__ v2f asm_copy(const v2f& src)
+{
+    v2f d;
+    asm volatile("v_mov_b64 %0, %1" : "=v"(d) : "v"(src));
+    return d;
 }
 template <int N, typename V>
 __device__ __forceinline__ void asm_wait2(V& a, V& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
