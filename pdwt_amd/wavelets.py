@@ -12,12 +12,59 @@ from . import _native as N
 W_INIT, W_FORWARD, W_INVERSE, W_THRESHOLD, W_CREATION_ERROR, W_FORWARD_ERROR, W_INVERSE_ERROR, W_THRESHOLD_ERROR = range(8)
 
 
+class DeviceArray:
+    """Zero-copy view of device memory owned by a ``Wavelets`` instance (``d_image`` or one band of ``d_coeffs``).
+
+    Exposes ``__cuda_array_interface__`` (v2; PyTorch-ROCm, CuPy-ROCm and numba consume it for HIP memory too):
+    ``torch.as_tensor(W.coeff_view(1), device="cuda")`` is a tensor over the band itself, no copy.  The view keeps
+    its owner alive.  The library works on its own stream: call ``Wavelets.sync()`` before the consumer reads and
+    synchronise the consumer's stream before the next transform (the reference's
+    ``image_int_ptr`` / ``coeff_int_ptr`` interop, src/wt.cu:660-667, with shape and dtype attached)."""
+
+    def __init__(self, owner, ptr, shape, dtype):
+        self._owner, self.ptr, self.shape, self.dtype = owner, int(ptr), tuple(int(v) for v in shape), np.dtype(dtype)
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False), "version": 2, "strides": None}
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if N.hip().pdwt_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), out.nbytes) != 0:
+            raise RuntimeError("device-to-host copy failed")
+        return out
+
+
+def _device_source(img):
+    """(pointer, shape, dtype) of an object that lives in device memory (torch tensor on the GPU or anything with
+    ``__cuda_array_interface__``), else None."""
+    if hasattr(img, "is_cuda") and hasattr(img, "data_ptr"):  # torch tensor, without importing torch here
+        if not img.is_cuda:
+            return None
+        if not img.is_contiguous():
+            raise ValueError("device tensors must be contiguous")
+        dt = {"torch.float32": np.float32, "torch.float64": np.float64}.get(str(img.dtype))
+        if dt is None:
+            raise TypeError("device tensors must be float32 or float64")
+        return int(img.data_ptr()), tuple(img.shape), np.dtype(dt)
+    cai = getattr(img, "__cuda_array_interface__", None)
+    if cai is not None:
+        if cai.get("strides") not in (None,):
+            raise ValueError("device arrays must be C-contiguous")
+        return int(cai["data"][0]), tuple(cai["shape"]), np.dtype(cai["typestr"])
+    return None
+
+
 class Wavelets:
     def __init__(self, img, wname, levels, do_separable=1, do_cycle_spinning=0, do_swt=0, ndim=2, dtype=None, shape=None, device_ptr=None):
         """Wavelets(img, Nr, Nc, wname, levels, memisonhost, do_separable, do_cycle_spinning, do_swt, ndim)
         (src/wt.h:42).  ``img`` is a 2-D (or 1-D) numpy array; or pass ``device_ptr`` + ``shape`` for
         an image already in HBM (memisonhost=0), or img=None + shape for a zero image."""
         N.require_gpu()
+        dev = _device_source(img) if img is not None else None
+        if dev is not None:  # image already in HBM: memisonhost = 0, the constructor copies device-to-device
+            device_ptr, shape, dtype = dev[0], (dev[1] if len(dev[1]) == 2 else (1, dev[1][0])), dev[2]
+            img = None
         if img is not None:
             img = np.asarray(img)
             if dtype is None:
@@ -165,7 +212,23 @@ class Wavelets:
             raise RuntimeError("get_image failed")
         return out
 
+    def sync(self):
+        """Wait for the library stream (everything enqueued by this process on the current device)."""
+        return N.hip().pdwt_sync()
+
+    def image_view(self):
+        """``d_image`` as a zero-copy DeviceArray (the reference's image_int_ptr with shape and dtype)."""
+        return DeviceArray(self, self.image_int_ptr(), self.shape, self.dtype)
+
+    def coeff_view(self, num):
+        """Band ``num`` of ``d_coeffs`` as a zero-copy DeviceArray (the reference's coeff_int_ptr)."""
+        return DeviceArray(self, self.coeff_int_ptr(num), self.band_shape(num), self.dtype)
+
     def set_image(self, img, mem_is_on_device=0):
+        dev = _device_source(img)
+        if dev is not None:
+            assert dev[2] == self.dtype and int(np.prod(dev[1])) == self.shape[0] * self.shape[1]
+            img, mem_is_on_device = dev[0], 1
         if mem_is_on_device:
             self._L.pdwt_wavelets_set_image(self._h, C.c_void_p(int(img)), 1)
         else:
@@ -183,6 +246,11 @@ class Wavelets:
 
     def set_coeff(self, arr, num):
         r, c = self.band_shape(num)
+        dev = _device_source(arr)
+        if dev is not None:
+            assert dev[2] == self.dtype and int(np.prod(dev[1])) == r * c
+            self._L.pdwt_wavelets_set_coeff(self._h, C.c_void_p(dev[0]), int(num), 1)
+            return
         a = np.ascontiguousarray(arr, dtype=self.dtype)
         assert a.size == r * c
         self._L.pdwt_wavelets_set_coeff(self._h, a.ctypes.data_as(C.c_void_p), int(num), 0)

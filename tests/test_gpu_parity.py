@@ -372,7 +372,7 @@ def test_cascade_equals_per_level(wname, monkeypatch):
     monkeypatch.setenv("PDWT_CASC_MIN", "0")
     rs = np.random.RandomState(29)
     L = pdwt_amd.hip()
-    for shape, levels in (((512, 512), 2), ((512, 768), 3), ((1024, 512), 4), ((256, 1280), 2), ((1096, 520), 3)):
+    for shape, levels in (((512, 512), 2), ((512, 768), 3), ((1024, 512), 4), ((256, 1280), 2), ((1096, 520), 3), ((2048, 3072), 3)):
         x = rs.uniform(0, 255, shape).astype(np.float32)
         res = []
         for casc in (1, 0):
@@ -388,10 +388,11 @@ def test_cascade_equals_per_level(wname, monkeypatch):
         for a, b in zip(res[0][0], res[1][0]):
             assert np.array_equal(a, b)
         assert np.array_equal(res[0][1], res[1][1])
-        O = orc.OracleWavelets(x, wname, levels)
-        O.forward()
-        for a, b in zip(res[0][0], O.coeffs):
-            assert band_err(a, b) <= TOL[np.dtype(np.float32)]
+        if x.size <= 1 << 21:
+            O = orc.OracleWavelets(x, wname, levels)
+            O.forward()
+            for a, b in zip(res[0][0], O.coeffs):
+                assert band_err(a, b) <= TOL[np.dtype(np.float32)]
 
 
 # ---- remaining coefficient utilities, custom filters, cycle spinning -------------------------
@@ -563,3 +564,38 @@ def test_circshift_and_cycle_spinning():
         assert band_err(g, o) <= 1e-10, k
     W.inverse()
     assert band_err(W.get_image(), x) <= 1e-10
+
+
+def test_zero_copy_interop_with_torch_tensors():
+    """image_int_ptr / coeff_int_ptr interop -- device tensors in, zero-copy views out."""
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    t = torch.rand((256, 384), generator=g, device="cuda", dtype=torch.float32) * 255
+    torch.cuda.synchronize()
+    W = pdwt_amd.Wavelets(t, "db4", 3)          # memisonhost = 0 path of the constructor
+    x = t.cpu().numpy()
+    assert np.array_equal(W.get_image(), x)
+    W.forward()
+    W.sync()
+    O = orc.OracleWavelets(x, "db4", 3)
+    O.forward()
+    for k in range(W.nbands):
+        v = torch.as_tensor(W.coeff_view(k), device="cuda")   # no copy: the tensor IS the band
+        assert v.data_ptr() == W.coeff_int_ptr(k) and tuple(v.shape) == W.band_shape(k)
+        assert band_err(v.cpu().numpy(), O.get_coeff(k)) <= TOL[np.dtype(np.float32)]
+    # edit a band in place from torch: the library sees it
+    d1 = torch.as_tensor(W.coeff_view(3), device="cuda")
+    d1.zero_()
+    torch.cuda.synchronize()
+    assert not W.get_coeff(3).any()
+    # hand a device tensor back as a band and as the image
+    W.set_coeff(torch.as_tensor(O.get_coeff(3)).cuda(), 3)
+    assert np.array_equal(W.get_coeff(3), O.get_coeff(3))
+    W.inverse()
+    W.sync()
+    rec = torch.as_tensor(W.image_view(), device="cuda")
+    assert band_err(rec.cpu().numpy(), x) <= TOL[np.dtype(np.float32)]
+    W.set_image(t * 2)
+    assert np.array_equal(W.get_image(), (t * 2).cpu().numpy())
+    assert np.array_equal(W.image_view().numpy(), W.get_image())
