@@ -132,7 +132,9 @@ def cpu_baseline(cfg, seconds_budget):
         dt = (time.perf_counter() - t0) / reps
         res[used] = dict(value=Nr * Nc / dt / 1e6, threads=used, reps=reps, s_per_pair=dt)
     best = max(res.values(), key=lambda r: r["value"])
+    pywt_ref = pywt_timing(cfg, Nr, Nc) if not cfg["extra"] else None
     return {
+        "pywt": pywt_ref,
         "value": round(best["value"], 2), "unit": cfg["unit"], "cores": best["threads"], "kind": "port",
         "sample": "%d x fwd+inv of a %dx%d %s %s L%d input (%s of the GPU workload's pixels per pair), oracle/pdwt_oracle.c with OpenMP, "
                   "best of thread counts %s" % (best["reps"], Nr, Nc, cfg["dtype"], cfg["wname"], W.info.nlevels,
@@ -140,6 +142,28 @@ def cpu_baseline(cfg, seconds_budget):
         "single_thread_value": round(res[1]["value"], 2), "host_cores": ncores,
         "by_threads": {str(k): round(v["value"], 1) for k, v in sorted(res.items())},
     }
+
+
+def pywt_timing(cfg, Nr, Nc):
+    """PyWavelets (the library BASELINE.json names as the parity reference) timed on the same sample, when a
+    python with pywt exists on this host ("probe at run time, never depend on it").  Single-threaded
+    by construction; None when unavailable.  Not the oracle and not the cpu_baseline value: context only."""
+    import subprocess
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py) or cfg["ndim"] != 2:
+        return None
+    code = ("import time,numpy as np,pywt\n"
+            "x=np.random.RandomState(0).uniform(0,255,(%d,%d)).astype('%s')\n"
+            "f=(lambda: pywt.iswt2(pywt.swt2(x,'%s',%d),'%s')) if %d else (lambda: pywt.waverec2(pywt.wavedec2(x,'%s','periodization',%d),'%s','periodization'))\n"
+            "f();t=time.perf_counter();f();print(time.perf_counter()-t)\n"
+            % (Nr, Nc, cfg["dtype"], cfg["wname"], cfg["levels"], cfg["wname"], cfg["do_swt"], cfg["wname"], cfg["levels"], cfg["wname"]))
+    try:
+        out = subprocess.run([py, "-c", code], capture_output=True, text=True, timeout=90)
+        dt = float(out.stdout.strip().splitlines()[-1])
+        return {"value": round(Nr * Nc / dt / 1e6, 2), "unit": cfg["unit"], "cores": 1, "s_per_pair": round(dt, 4),
+                "what": "pywt wavedec2+waverec2 (or swt2+iswt2) on the same %dx%d sample" % (Nr, Nc)}
+    except Exception:
+        return None
 
 
 def main():
