@@ -261,7 +261,7 @@ int FN(orc_forward_separable)(const T* image, T** c, T* tmp, orc_info w, const F
 /* w_inverse_separable, src/separable.cu:332-364 */
 int FN(orc_inverse_separable)(T* image, T** c, T* tmp, orc_info w, const FILTERS* f)
 {
-    int tNr[64], tNc[64];
+    int tNr[64] = {0}, tNc[64] = {0};
     tNr[0] = w.Nr; tNc[0] = w.Nc;
     for (int i = 1; i <= w.nlevels; i++) { tNr[i] = orc_div2(tNr[i - 1]); tNc[i] = orc_div2(tNc[i - 1]); }
     T* t1 = tmp;
@@ -297,7 +297,7 @@ int FN(orc_forward_separable_1d)(const T* image, T** c, T* tmp, orc_info w, cons
 /* w_inverse_separable_1d, src/separable.cu:368-395 */
 int FN(orc_inverse_separable_1d)(T* image, T** c, T* tmp, orc_info w, const FILTERS* f)
 {
-    int tNc[64];
+    int tNc[64] = {0};
     tNc[0] = w.Nc;
     for (int i = 1; i <= w.nlevels; i++) tNc[i] = orc_div2(tNc[i - 1]);
     T* bufs[2] = { tmp, tmp + (size_t)w.Nr * tNc[1] };
@@ -427,7 +427,7 @@ int FN(orc_haar_forward2d)(const T* image, T** c, T* tmp, orc_info w)
 /* haar_inverse2d, src/haar.cu:88-119 */
 int FN(orc_haar_inverse2d)(T* image, T** c, T* tmp, orc_info w)
 {
-    int tNr[64], tNc[64];
+    int tNr[64] = {0}, tNc[64] = {0};
     tNr[0] = w.Nr; tNc[0] = w.Nc;
     for (int i = 1; i <= w.nlevels; i++) { tNr[i] = orc_div2(tNr[i - 1]); tNc[i] = orc_div2(tNc[i - 1]); }
     T* bufs[2] = { tmp, tmp + (size_t)tNr[1] * tNc[1] };
@@ -483,7 +483,7 @@ int FN(orc_haar_forward1d)(const T* image, T** c, T* tmp, orc_info w)
 /* haar_inverse1d, src/haar.cu:193-221 */
 int FN(orc_haar_inverse1d)(T* image, T** c, T* tmp, orc_info w)
 {
-    int tNc[64];
+    int tNc[64] = {0};
     tNc[0] = w.Nc;
     for (int i = 1; i <= w.nlevels; i++) tNc[i] = orc_div2(tNc[i - 1]);
     T* bufs[2] = { tmp, tmp + (size_t)w.Nr * tNc[1] };
