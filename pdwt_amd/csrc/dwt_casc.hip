@@ -570,7 +570,7 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
     return PDWT_OK;
 }
 
-#define PDWT_CASC_FWD_HLENS(X) X(4) X(6) X(8) X(10)
+#define PDWT_CASC_FWD_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
 
 int fwd2d_casc_f32(const float* in, float* H1, float* V1, float* D1, float* A2, float* H2, float* V2, float* D2, float* trash, int nr,
                    int nc, int hlen, const Taps2<float>& f)
@@ -605,17 +605,26 @@ static int launch_inv_casc(const CascInvBands& b, float* out, float* trash, int 
     constexpr int H2 = HLEN / 2;
     // prefetch distance in steps: 1 measured best (28.2 us vs 29.5 @2, 31.5 @H2 for 4096^2 db4, 2048 waves)
     const int pfd = env_int("PDWT_CASC_IPFD", 1);
-    if (pfd == 1)
-        hipLaunchKernelGGL((k_inv2d_casc<HLEN, 1>), grid, dim3(256), 0, stream(), b, out, nr, nc, VL, trash, cm, f);
-    else if (pfd < H2 && H2 % 2 == 0)
-        hipLaunchKernelGGL((k_inv2d_casc<HLEN, (H2 % 2 == 0 ? H2 / 2 : H2)>), grid, dim3(256), 0, stream(), b, out, nr, nc, VL, trash, cm, f);
-    else
-        hipLaunchKernelGGL((k_inv2d_casc<HLEN, H2>), grid, dim3(256), 0, stream(), b, out, nr, nc, VL, trash, cm, f);
+    bool launched = false;
+    if constexpr (H2 % 2 == 0) {
+        if (pfd == 2) {
+            hipLaunchKernelGGL((k_inv2d_casc<HLEN, 2>), grid, dim3(256), 0, stream(), b, out, nr, nc, VL, trash, cm, f);
+            launched = true;
+        }
+    }
+    if constexpr (H2 * 14 - 3 <= 63 && H2 > 2) {  // a whole ring period ahead only while vmcnt can count that far
+        if (pfd >= H2 && !launched) {
+            hipLaunchKernelGGL((k_inv2d_casc<HLEN, H2>), grid, dim3(256), 0, stream(), b, out, nr, nc, VL, trash, cm, f);
+            launched = true;
+        }
+    }
+    if (!launched) hipLaunchKernelGGL((k_inv2d_casc<HLEN, 1>), grid, dim3(256), 0, stream(), b, out, nr, nc, VL, trash, cm, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
 
-#define PDWT_CASC_INV_HLENS(X) X(4) X(6) X(8)
+// (hlen >= 12: two single-level launches are faster in this direction -- 37.9 vs 41.3 us db6, 52.4 vs 59.6 us db8 at 4096^2)
+#define PDWT_CASC_INV_HLENS(X) X(4) X(6) X(8) X(10)
 
 int inv2d_casc_f32(const float* A2, const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1,
                    float* out, float* trash, int nr, int nc, int hlen, const Taps2<float>& f)

@@ -438,8 +438,12 @@ template <int HLEN>
 static int launch_fwd(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, int nr, int nc, const Taps2<float>& f)
 {
     const long long narrow_below = env_int("PDWT_STREAM_NARROW", 2048 * 2048);
-    if ((long long)nr * nc <= narrow_below) return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, trash, nr, nc, f);
-    return launch_fwd_n<HLEN, 4>(in, cA, cH, cV, cD, trash, nr, nc, f);
+    if constexpr (HLEN > 10) {  // the wide form would need 2*HLEN row + 2*HLEN ring register pairs: narrow lanes only
+        return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, trash, nr, nc, f);
+    } else {
+        if ((long long)nr * nc <= narrow_below) return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, trash, nr, nc, f);
+        return launch_fwd_n<HLEN, 4>(in, cA, cH, cV, cD, trash, nr, nc, f);
+    }
 }
 
 template <int HLEN>
@@ -458,7 +462,7 @@ static int launch_inv(const float* cA, const float* cH, const float* cV, const f
 }
 
 // filter lengths with a streaming instantiation (register budget: one unrolled body holds HLEN rows in flight)
-#define PDWT_STREAM_FWD_HLENS(X) X(4) X(6) X(8) X(10)
+#define PDWT_STREAM_FWD_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
 #define PDWT_STREAM_INV_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
 
 int fwd2d_stream_f32(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, int nr, int nc, int hlen,

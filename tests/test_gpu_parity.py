@@ -365,7 +365,7 @@ def test_fused_small_levels_equal_per_level(wname):
         assert np.array_equal(res[0][1], res[1][1])
 
 
-@pytest.mark.parametrize("wname", ["db2", "db3", "db4", "db5"])
+@pytest.mark.parametrize("wname", ["db2", "db3", "db4", "db5", "db6", "db7", "sym8"])
 def test_cascade_equals_per_level(wname, monkeypatch):
     """dwt_casc.hip (two levels per launch, approximation kept in registers) is the same arithmetic as one launch per level,
     and both match the oracle."""
