@@ -188,6 +188,205 @@ __global__ __launch_bounds__(256) void k_syn_cols_ring(const T* __restrict__ ca,
 }
 
 // -------------------------------------------------------------------------------------------------
+// Long filters: taps in a VGPR, broadcast by v_readlane ("_tr" kernels).
+// The kernels above take the taps from the kernarg segment, i.e. from SGPRs.  2*HLEN taps of a long bank do not
+// fit the ~100 SGPRs of a wave (db20 in double: 160) and, because every tap is used in every unrolled row of the
+// ring period, all of them are live at once: hipcc parks them in VGPR lanes and fetches them back with TWO
+// v_readlane per use (measured: 5544 v_readlane for 2240 FMAs in k_syn_cols_ring<double,40>).  Here lane k of
+// one register holds tap k, a GROUP of G rows is computed tap-major (read a tap once, feed it to G rows, drop
+// it), and an opaque barrier per group keeps the compiler from hoisting the reads back into one live set:
+// 2 v_readlane per 2*G FMAs instead of per FMA.  Each accumulator still sums its taps in ascending order.
+// -------------------------------------------------------------------------------------------------
+constexpr int kTapG = 4;  // rows per tap-major group
+
+__device__ __forceinline__ float lane_bcast(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+__device__ __forceinline__ double lane_bcast(double v, int k)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, k);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), k);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <typename T> __device__ __forceinline__ void opaque(T& v) { asm volatile("" : "+v"(v)); }
+// zero-instruction ordering point: the tap registers pass through it together with one accumulator of the previous
+// tap, so the next tap's v_readlanes cannot be scheduled above the previous tap's FMAs (hoisted together, the reads
+// need every SGPR at once and hipcc spills them straight back into VGPR lanes)
+template <typename T> __device__ __forceinline__ void tap_order(T& ta, T& tb, T (&a)[8])
+{
+    asm volatile("" : "+v"(ta), "+v"(tb), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+}
+
+template <typename T, int HLEN, int CPL>
+__global__ __launch_bounds__(256) void k_ana_cols_ring_tr(const T* __restrict__ t, T* __restrict__ lo, T* __restrict__ hi, int Nr, int Ncw,
+                                                           int RO, Taps2<T> f)
+{
+    using V = typename VecT<T, CPL>::type;
+    constexpr int G = kTapG;
+    constexpr int C = HLEN / 2 - 1;
+    constexpr int RS = ((HLEN + 2 * G - 2 + 2 * G - 1) / (2 * G)) * (2 * G);  // >= HLEN + 2G - 2 (last row of a group), RS/2 % G == 0
+    static_assert(HLEN <= 64, "one tap per lane");
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int x0 = (strip * 64 + lane) * CPL;
+    if (strip * 64 * CPL >= Ncw) return;
+    const bool active = x0 < Ncw;
+    const int xl = active ? x0 : 0;
+    const int Nr2 = div2(Nr);
+    const int y0 = blockIdx.y * RO;
+    const int nout = min(RO, Nr2 - y0);
+    if (nout <= 0) return;
+    const int rb = 2 * y0 - C;
+    const int nin = 2 * nout + HLEN - 2;
+    T tapA = f.a[min(lane, HLEN - 1)], tapB = f.b[min(lane, HLEN - 1)];  // lane k <- tap k
+
+    V ring[RS];
+    auto row_ptr = [&](int r) { return reinterpret_cast<const V*>(t + (size_t)wrap_ext(rb + min(r, nin - 1), Nr) * Ncw + xl); };
+    cfor<RS>([&](auto S) { ring[decltype(S)::value] = *row_ptr(decltype(S)::value); });
+
+    for (int q0 = 0; q0 < nout; q0 += RS / 2) {
+        cfor<RS / 2 / G>([&](auto GG) {
+            constexpr int u0 = decltype(GG)::value * G;
+            static_assert(CPL == 1 && G == 4, "accumulator layout of tap_order");
+            T acc[8];  // [2r] = lo of row r, [2r+1] = hi of row r
+#pragma unroll
+            for (int r = 0; r < 8; r++) acc[r] = T(0);
+            cfor<HLEN>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                tap_order(tapA, tapB, acc);
+                const T fl = lane_bcast(tapA, HLEN - 1 - j), fh = lane_bcast(tapB, HLEN - 1 - j);
+                cfor<G>([&](auto Rr) {
+                    constexpr int r = decltype(Rr)::value;
+                    constexpr int s = (2 * (u0 + r) + j) % RS;
+                    const T v = ring[s];
+                    acc[2 * r] = fma_t(v, fl, acc[2 * r]);
+                    acc[2 * r + 1] = fma_t(v, fh, acc[2 * r + 1]);
+                });
+            });
+            T al[G][CPL], ah[G][CPL];
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+                al[r][0] = acc[2 * r];
+                ah[r][0] = acc[2 * r + 1];
+            }
+            cfor<G>([&](auto Rr) {
+                constexpr int r = decltype(Rr)::value;
+                const int q = q0 + u0 + r;
+                if (q < nout && active) {
+                    V vl, vh;
+#pragma unroll
+                    for (int p = 0; p < CPL; p++) {
+                        vset<T, CPL>(vl, p, al[r][p]);
+                        vset<T, CPL>(vh, p, ah[r][p]);
+                    }
+                    const size_t o = (size_t)(y0 + q) * Ncw + x0;
+                    *reinterpret_cast<V*>(lo + o) = vl;
+                    *reinterpret_cast<V*>(hi + o) = vh;
+                }
+            });
+            // the 2G rows the group consumed first are dead: their slots take the rows RS ahead (clamped)
+            cfor<2 * G>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                ring[(2 * u0 + i) % RS] = *row_ptr(2 * (q0 + u0) + i + RS);
+            });
+        });
+    }
+}
+
+template <typename T, int HLEN, int CPL>
+__global__ __launch_bounds__(256) void k_syn_cols_ring_tr(const T* __restrict__ ca, const T* __restrict__ cd, T* __restrict__ out, int Nri,
+                                                           int Nc, int Nro, int RQ, Taps2<T> f)
+{
+    using V = typename VecT<T, CPL>::type;
+    constexpr int G = kTapG;
+    constexpr int H2 = HLEN / 2;
+    constexpr int C = H2 / 2;
+    constexpr int SHIFT = (H2 & 1) ? 0 : 1;
+    constexpr int RS = ((H2 + 7 + G - 1) / G) * G;  // >= H2 + G - 1, RS % G == 0, >= 4 rows of prefetch distance
+    static_assert(HLEN <= 64, "one tap per lane");
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int x0 = (strip * 64 + lane) * CPL;
+    if (strip * 64 * CPL >= Nc) return;
+    const bool active = x0 < Nc;
+    const int xl = active ? x0 : 0;
+    const int y0 = blockIdx.y * RQ;
+    const int nq = min(RQ, Nri - y0);
+    if (nq <= 0) return;
+    const int rb = y0 - C;
+    const int nrows = nq + H2 - 1 + SHIFT;
+    const int nsteps = nq + SHIFT;
+    T tapA = f.a[min(lane, HLEN - 1)], tapB = f.b[min(lane, HLEN - 1)];
+
+    V ra[RS], rd[RS];
+    auto off_of = [&](int r) { return (size_t)wrap_per(rb + min(r, nrows - 1), Nri) * Nc + xl; };
+    cfor<RS>([&](auto S) {
+        const size_t o = off_of(decltype(S)::value);
+        ra[decltype(S)::value] = *reinterpret_cast<const V*>(ca + o);
+        rd[decltype(S)::value] = *reinterpret_cast<const V*>(cd + o);
+    });
+
+    for (int t0 = 0; t0 < nsteps; t0 += RS) {
+        cfor<RS / G>([&](auto GG) {
+            constexpr int u0 = decltype(GG)::value * G;
+            static_assert(CPL == 1 && G == 4, "accumulator layout of tap_order");
+            T acc[2][8];  // [e][2r] = a-branch, [e][2r+1] = d-branch of step r; e = 0: tap parity 1 (row g1), 1: parity 0 (row g0)
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) acc[e][r] = T(0);
+            cfor<H2>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                cfor<2>([&](auto E) {
+                    constexpr int e = decltype(E)::value;
+                    constexpr int k = HLEN - 1 - (2 * j + (1 - e));
+                    tap_order(tapA, tapB, acc[e]);
+                    const T fl = lane_bcast(tapA, k), fh = lane_bcast(tapB, k);
+                    cfor<G>([&](auto Rr) {
+                        constexpr int r = decltype(Rr)::value;
+                        constexpr int s = (u0 + r + j) % RS;
+                        acc[e][2 * r] = fma_t(ra[s], fl, acc[e][2 * r]);
+                        acc[e][2 * r + 1] = fma_t(rd[s], fh, acc[e][2 * r + 1]);
+                    });
+                });
+            });
+            T sa[G][2][CPL], sd[G][2][CPL];
+#pragma unroll
+            for (int r = 0; r < G; r++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    sa[r][e][0] = acc[e][2 * r];
+                    sd[r][e][0] = acc[e][2 * r + 1];
+                }
+            cfor<G>([&](auto Rr) {
+                constexpr int r = decltype(Rr)::value;
+                const int tt = t0 + u0 + r;
+                if (tt < nsteps && active) {
+                    const int g1 = 2 * tt - SHIFT, g0 = g1 + 1;
+                    if (g1 >= 0 && g1 < 2 * nq && 2 * y0 + g1 < Nro) {
+                        V v;
+#pragma unroll
+                        for (int p = 0; p < CPL; p++) vset<T, CPL>(v, p, sa[r][0][p] + sd[r][0][p]);
+                        *reinterpret_cast<V*>(out + (size_t)(2 * y0 + g1) * Nc + x0) = v;
+                    }
+                    if (g0 < 2 * nq && 2 * y0 + g0 < Nro) {
+                        V v;
+#pragma unroll
+                        for (int p = 0; p < CPL; p++) vset<T, CPL>(v, p, sa[r][1][p] + sd[r][1][p]);
+                        *reinterpret_cast<V*>(out + (size_t)(2 * y0 + g0) * Nc + x0) = v;
+                    }
+                }
+            });
+            cfor<G>([&](auto Rr) {
+                constexpr int r = decltype(Rr)::value;
+                const size_t o = off_of(t0 + u0 + r + RS);
+                ra[(u0 + r) % RS] = *reinterpret_cast<const V*>(ca + o);
+                rd[(u0 + r) % RS] = *reinterpret_cast<const V*>(cd + o);
+            });
+        });
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Stationary (a-trous) column passes, level with tap spacing f = 2^(level-1).  Rows r = rho (mod f) form
 // f independent sub-signals of M = Nr/f samples on which the dilated filter is an ordinary dense filter
 // (the periodic wrap stays inside a residue class because f divides Nr): one wave = one column strip x one
@@ -337,7 +536,11 @@ static int launch_ana(const T* t, T* lo, T* hi, int Nr, int Ncw, const Taps2<T>&
     const int strips = idiv_up(Ncw, 64 * CPL);
     const int RO = pick_chunk(div2(Nr), strips, HLEN);
     dim3 grid(idiv_up(strips, 4), idiv_up(div2(Nr), RO));
-    hipLaunchKernelGGL((k_ana_cols_ring<T, HLEN, CPL>), grid, dim3(256), 0, stream(), t, lo, hi, Nr, Ncw, RO, f);
+    // taps beyond the SGPR budget: VGPR tap register + v_readlane (k_*_tr above)
+    if constexpr (sizeof(T) == 8 && HLEN >= 20 && CPL == 1)
+        hipLaunchKernelGGL((k_ana_cols_ring_tr<T, HLEN, CPL>), grid, dim3(256), 0, stream(), t, lo, hi, Nr, Ncw, RO, f);
+    else
+        hipLaunchKernelGGL((k_ana_cols_ring<T, HLEN, CPL>), grid, dim3(256), 0, stream(), t, lo, hi, Nr, Ncw, RO, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -347,7 +550,10 @@ static int launch_syn(const T* ca, const T* cd, T* out, int Nri, int Nc, int Nro
     const int strips = idiv_up(Nc, 64 * CPL);
     const int RQ = pick_chunk(Nri, strips, HLEN / 2);
     dim3 grid(idiv_up(strips, 4), idiv_up(Nri, RQ));
-    hipLaunchKernelGGL((k_syn_cols_ring<T, HLEN, CPL>), grid, dim3(256), 0, stream(), ca, cd, out, Nri, Nc, Nro, RQ, f);
+    if constexpr (sizeof(T) == 8 && HLEN >= 20 && CPL == 1)
+        hipLaunchKernelGGL((k_syn_cols_ring_tr<T, HLEN, CPL>), grid, dim3(256), 0, stream(), ca, cd, out, Nri, Nc, Nro, RQ, f);
+    else
+        hipLaunchKernelGGL((k_syn_cols_ring<T, HLEN, CPL>), grid, dim3(256), 0, stream(), ca, cd, out, Nri, Nc, Nro, RQ, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
