@@ -340,71 +340,75 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
     // one output row of level l from the ring window starting at slot S0 with tap parity OFF (cf. k_inv2d_stream::emit)
     auto emit = [&](auto S0, auto OFF, int g) {
         constexpr int s0 = decltype(S0)::value, off = decltype(OFF)::value;
-        v2f sa = {0.f, 0.f}, sh = {0.f, 0.f}, sv = {0.f, 0.f}, sd = {0.f, 0.f};
-        static_for<H2>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            constexpr int s = (s0 + j) % H2;
-            constexpr int k = HLEN - 1 - (2 * j + off);
-            const v2f fl = splat(f.a[k]), fh = splat(f.b[k]);
-            sa = pk_fma(ra[s], fl, sa);
-            sh = pk_fma(rh[s], fh, sh);
-            sv = pk_fma(rv[s], fl, sv);
-            sd = pk_fma(rd[s], fh, sd);
-        });
-        const v2f t1o = sa + sh, t2o = sv + sd;
-        float t1[WIN1], t2[WIN1];
-        t1[NB1 * 2] = t1o.x;
-        t1[NB1 * 2 + 1] = t1o.y;
-        t2[NB1 * 2] = t2o.x;
-        t2[NB1 * 2 + 1] = t2o.y;
-#pragma unroll
-        for (int k = 0; k < NB1; k++) {
-            const int dl = (NB1 - 1 - k) * 2, sl = (NB1 - k) * 2, dr = (NB1 + 1 + k) * 2, sr = (NB1 + k) * 2;
-#pragma unroll
-            for (int cc = 0; cc < 2; cc++) {
-                t1[dl + cc] = dpp_shr1(t1[sl + cc]);
-                t2[dl + cc] = dpp_shr1(t2[sl + cc]);
-                t1[dr + cc] = dpp_shl1(t1[sr + cc]);
-                t2[dr + cc] = dpp_shl1(t2[sr + cc]);
+        // rows of the ring warm-up / beyond the chunk: the store is still issued (to a trash row, the VMEM count must not
+        // change) but the arithmetic is skipped -- a uniform branch, 8 of the ~46 emits of a wave
+        const bool own = (g >= 0) && (g < 2 * rows1);
+        float o4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (own) {
+            v2f sa = {0.f, 0.f}, sh = {0.f, 0.f}, sv = {0.f, 0.f}, sd = {0.f, 0.f};
+            static_for<H2>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                constexpr int s = (s0 + j) % H2;
+                constexpr int k = HLEN - 1 - (2 * j + off);
+                const v2f fl = splat(f.a[k]), fh = splat(f.b[k]);
+                sa = pk_fma(ra[s], fl, sa);
+                sh = pk_fma(rh[s], fh, sh);
+                sv = pk_fma(rv[s], fl, sv);
+                sd = pk_fma(rd[s], fh, sd);
+            });
+            const v2f t1o = sa + sh, t2o = sv + sd;
+            float t1[WIN1], t2[WIN1];
+            t1[NB1 * 2] = t1o.x;
+            t1[NB1 * 2 + 1] = t1o.y;
+            t2[NB1 * 2] = t2o.x;
+            t2[NB1 * 2 + 1] = t2o.y;
+    #pragma unroll
+            for (int k = 0; k < NB1; k++) {
+                const int dl = (NB1 - 1 - k) * 2, sl = (NB1 - k) * 2, dr = (NB1 + 1 + k) * 2, sr = (NB1 + k) * 2;
+    #pragma unroll
+                for (int cc = 0; cc < 2; cc++) {
+                    t1[dl + cc] = dpp_shr1(t1[sl + cc]);
+                    t2[dl + cc] = dpp_shr1(t2[sl + cc]);
+                    t1[dr + cc] = dpp_shl1(t1[sr + cc]);
+                    t2[dr + cc] = dpp_shl1(t2[sr + cc]);
+                }
+            }
+            auto pair_out = [&](auto E0) {
+                constexpr int e0 = decltype(E0)::value;
+                constexpr int pl = (e0 + SHIFT) >> 1;
+                v2f s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+    #pragma unroll
+                for (int j = 0; j < H2; j++) {
+                    const int m = HLEN - 1 - 2 * j;
+                    s1 = pk_fma(splat(t1[NB1 * 2 + pl - C + j]), v2f{f.a[m - 1], f.a[m]}, s1);
+                    s2 = pk_fma(splat(t2[NB1 * 2 + pl - C + j]), v2f{f.b[m - 1], f.b[m]}, s2);
+                }
+                const v2f o = s1 + s2;
+                o4[e0] = o.x;
+                o4[e0 + 1] = o.y;
+            };
+            auto single_out = [&](auto E) {
+                constexpr int eo = decltype(E)::value;
+                constexpr int gp = eo + SHIFT;
+                constexpr int pl = gp >> 1, offx = 1 - (gp & 1);
+                float s1 = 0.f, s2 = 0.f;
+    #pragma unroll
+                for (int j = 0; j < H2; j++) {
+                    const int k = HLEN - 1 - (2 * j + offx);
+                    s1 = __builtin_fmaf(t1[NB1 * 2 + pl - C + j], f.a[k], s1);
+                    s2 = __builtin_fmaf(t2[NB1 * 2 + pl - C + j], f.b[k], s2);
+                }
+                o4[eo] = s1 + s2;
+            };
+            if constexpr (SHIFT == 0) {
+                pair_out(std::integral_constant<int, 0>{});
+                pair_out(std::integral_constant<int, 2>{});
+            } else {
+                single_out(std::integral_constant<int, 0>{});
+                pair_out(std::integral_constant<int, 1>{});
+                single_out(std::integral_constant<int, 3>{});
             }
         }
-        float o4[4];
-        auto pair_out = [&](auto E0) {
-            constexpr int e0 = decltype(E0)::value;
-            constexpr int pl = (e0 + SHIFT) >> 1;
-            v2f s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < H2; j++) {
-                const int m = HLEN - 1 - 2 * j;
-                s1 = pk_fma(splat(t1[NB1 * 2 + pl - C + j]), v2f{f.a[m - 1], f.a[m]}, s1);
-                s2 = pk_fma(splat(t2[NB1 * 2 + pl - C + j]), v2f{f.b[m - 1], f.b[m]}, s2);
-            }
-            const v2f o = s1 + s2;
-            o4[e0] = o.x;
-            o4[e0 + 1] = o.y;
-        };
-        auto single_out = [&](auto E) {
-            constexpr int eo = decltype(E)::value;
-            constexpr int gp = eo + SHIFT;
-            constexpr int pl = gp >> 1, offx = 1 - (gp & 1);
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < H2; j++) {
-                const int k = HLEN - 1 - (2 * j + offx);
-                s1 = __builtin_fmaf(t1[NB1 * 2 + pl - C + j], f.a[k], s1);
-                s2 = __builtin_fmaf(t2[NB1 * 2 + pl - C + j], f.b[k], s2);
-            }
-            o4[eo] = s1 + s2;
-        };
-        if constexpr (SHIFT == 0) {
-            pair_out(std::integral_constant<int, 0>{});
-            pair_out(std::integral_constant<int, 2>{});
-        } else {
-            single_out(std::integral_constant<int, 0>{});
-            pair_out(std::integral_constant<int, 1>{});
-            single_out(std::integral_constant<int, 3>{});
-        }
-        const bool own = (g >= 0) && (g < 2 * rows1);  // uniform: rows of the ring warm-up / beyond the chunk go to a trash row
         asm_store_sm(own ? out + (size_t)wrap1(2 * ya + g, Nr) * Nc : tr, voffo, v4f{o4[0], o4[1], o4[2], o4[3]}, vmask);
     };
 
