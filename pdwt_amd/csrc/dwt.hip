@@ -4,7 +4,12 @@
 // and the four level drivers).  Math: SURVEY.md Appendix A-1 / A-2; the per-sample tap order and the
 // one-FMA-per-tap accumulation are the reference's, so results are bit-identical to the CPU oracle.
 //
-// MI355X design (not the reference's 16x16-thread, one-global-load-per-tap structure):
+// This file holds the GENERAL kernels (any size, any hlen <= 40, float and double) and the level drivers.  The
+// drivers try the specialised float32 paths first -- two levels per launch (dwt_casc.hip), one streaming launch
+// per level (dwt_stream.hip), all levels of a batched-1D row in one launch (dwt1d_fused.hip), register-ring
+// column passes (cols_ring.hip) -- and fall back to the kernels below for geometries those do not take.
+//
+// MI355X design of the general kernels (not the reference's 16x16-thread, one-global-load-per-tap structure):
 //   * one FUSED kernel per level for 2D (row pass + column pass through LDS): every input sample is
 //     read from HBM once per level (+ tile halo), the four bands are written once; the reference
 //     round-trips two half-width temporaries through memory per level;

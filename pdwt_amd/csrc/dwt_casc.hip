@@ -10,10 +10,10 @@
 //   pass (halo from neighbouring lanes by DPP, as for the input) into ring2;
 //   every 4 input rows: one row of A2,H2,V2,D2 (4-byte stores).
 // Halo: NB1 lanes (input) + NB2 lanes (A1) per side -> 58 producing lanes of 64 for hlen 8; vertically a
-// chunk of R2 level-(l+1) rows recomputes hlen-2 rows of A1 (and reads 3(hlen-2) extra input rows, L2 hits).
-// The loop is branch-free: every store is always issued (halo lanes, rows outside the chunk's own range
-// and the ring warm-up go to a trash slot), so the hand-counted s_waitcnt pipeline of dwt_stream.hip
-// carries over with per-position constants (casc_after).
+// chunk of level-(l+1) rows recomputes hlen-2 rows of A1 (and re-reads 3(hlen-2) input rows).
+// The loop issues every store unconditionally: lanes that own no output are masked through EXEC, rows
+// outside the chunk's own range and the ring warm-up go to a trash row (a scalar select of the base), so the
+// hand-counted s_waitcnt pipeline of dwt_stream.hip carries over with per-position constants (casc_fwd_after).
 // Arithmetic per sample = the single-level kernels' (row pass then column pass, taps ascending, one FMA
 // per tap), so the result is bit-identical to running the two levels separately.
 // Reference code replaced: two iterations of the level loop of w_forward_separable / w_inverse_separable
