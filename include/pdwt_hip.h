@@ -213,6 +213,24 @@ int pdwt_norm1_as_double_f64(double** d_coeffs, pdwt_info info, double* out);
 PDWT_DECL_UTILS(float, f32)
 PDWT_DECL_UTILS(double, f64)
 
+/* ---------------------------------------------------------------------------------------------
+ * Non-separable 2-D transform with four arbitrary hlen x hlen kernels (custom banks only).
+ *   <- w_forward / w_inverse / w_forward_swt / w_inverse_swt  src/nonseparable.cu:233-292, 408-452
+ *      (+ kernels :114-226, 301-400).
+ * d_kernels: DEVICE pointer to 4*hlen*hlen taps, row-major [y][x], in the order LL, LH, HL, HH -- the
+ * contents of the reference's c_kern_LL/LH/HL/HH constant arrays (src/nonseparable.cu:7-11) -- the forward
+ * set for the forward calls, the inverse set for the inverse calls.  Same d_image / d_coeffs / d_tmp contract
+ * as the separable drivers.  For the named wavelets (outer-product kernels) use the separable drivers on a
+ * band table with H and V exchanged instead: same result, O(hlen) per sample.
+ * ------------------------------------------------------------------------------------------- */
+#define PDWT_DECL_NONSEP(T, S)                                                                                     \
+    int pdwt_forward_nonseparable_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info, const T* d_kernels);     \
+    int pdwt_inverse_nonseparable_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info, const T* d_kernels);     \
+    int pdwt_forward_swt_nonseparable_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info, const T* d_kernels); \
+    int pdwt_inverse_swt_nonseparable_##S(T* d_image, T** d_coeffs, T* d_tmp, pdwt_info info, const T* d_kernels);
+PDWT_DECL_NONSEP(float, f32)
+PDWT_DECL_NONSEP(double, f64)
+
 #ifdef __cplusplus
 }
 #endif

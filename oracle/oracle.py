@@ -34,6 +34,16 @@ Filters32 = _filters_struct(C.c_float)
 Filters64 = _filters_struct(C.c_double)
 
 
+def _filters2d_struct(ct):
+    class F2(C.Structure):  # four hlen x hlen kernels (LL, LH, HL, HH), src/nonseparable.cu:7-11
+        _fields_ = [("hlen", C.c_int), ("K", (ct * 1600) * 4)]
+    return F2
+
+
+Filters2D32 = _filters2d_struct(C.c_float)
+Filters2D64 = _filters2d_struct(C.c_double)
+
+
 def build(force=False):
     so = os.path.join(_HERE, "libpdwt_oracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("pdwt_oracle.c", "pdwt_oracle_impl.h")]
@@ -100,7 +110,7 @@ def band_shapes(Nr, Nc, nlevels, do_swt, ndims):
 class OracleWavelets:
     """Host mirror of the reference's Wavelets class, computing with the C oracle."""
 
-    def __init__(self, img, wname, levels, do_swt=0, ndim=2, dtype=None, custom_filters=None):
+    def __init__(self, img, wname, levels, do_swt=0, ndim=2, dtype=None, custom_filters=None, do_separable=1):
         img = np.asarray(img)
         if dtype is None:
             dtype = img.dtype if img.dtype in (np.float32, np.float64) else np.float32
@@ -116,6 +126,8 @@ class OracleWavelets:
             ndim = 1
         self.wname = wname
         self.do_swt = int(do_swt)
+        self.do_separable = 1 if (ndim == 1 or Nr == 1) else int(do_separable)  # src/wt.cu:137-141: ignored in 1-D
+        self._F2 = None  # custom non-separable kernels: (forward Filters2D, inverse Filters2D)
         if custom_filters is not None:
             hlen, self._F = custom_filters
         else:
@@ -151,7 +163,51 @@ class OracleWavelets:
             return "haar_%s%dd" % (direction, i.ndims), False
         return direction + ("_swt" if i.do_swt else "") + "_separable" + ("_1d" if i.ndims == 1 else ""), True
 
+    def _filters2d(self, direction):
+        """The four 2-D kernels of the non-separable path: custom ones if set, else the outer products of the 1-D
+        bank (w_compute_filters(wname, +1 | -1), src/nonseparable.cu:32-83; src/wt.cu:296 reloads them for the inverse)."""
+        if self._F2 is not None:
+            return self._F2[0 if direction == "forward" else 1]
+        F2 = (Filters2D32 if self.dtype == np.float32 else Filters2D64)()
+        lo, hi = (self._F.L, self._F.H) if direction == "forward" else (self._F.IL, self._F.IH)
+        getattr(lib(), "orc_outer_filters_" + self.sfx)(lo, hi, self.info.hlen, C.byref(F2))
+        return F2
+
+    def set_filters_forward_nonseparable(self, name, k_ll, k_lh, k_hl, k_hh):  # src/wt.cu:560-581, nonseparable.cu:86-95
+        ks = [np.asarray(k, dtype=self.dtype) for k in (k_ll, k_lh, k_hl, k_hh)]
+        n = ks[0].shape[0]
+        F2f = (Filters2D32 if self.dtype == np.float32 else Filters2D64)()
+        F2f.hlen = n
+        for b in range(4):
+            flat = ks[b].reshape(-1)
+            for i in range(n * n):
+                F2f.K[b][i] = flat[i]
+        self._F2 = (F2f, None)
+        self.info.hlen = n
+        self.wname = name
+        return 0
+
+    def set_filters_inverse_nonseparable(self, k_ll, k_lh, k_hl, k_hh):  # src/wt.cu:584-602
+        ks = [np.asarray(k, dtype=self.dtype) for k in (k_ll, k_lh, k_hl, k_hh)]
+        n = self.info.hlen
+        F2i = (Filters2D32 if self.dtype == np.float32 else Filters2D64)()
+        F2i.hlen = n
+        for b in range(4):
+            flat = ks[b].reshape(-1)
+            for i in range(n * n):
+                F2i.K[b][i] = flat[i]
+        self._F2 = (self._F2[0], F2i)
+        return 0
+
     def _call(self, direction):
+        i = self.info
+        if not self.do_separable and i.ndims == 2 and not (i.hlen == 2 and not i.do_swt and self._F2 is None):
+            # Wavelets::forward/inverse, do_separable == 0 branch (src/wt.cu:257-260, 294-299)
+            fn = getattr(lib(), "orc_%s%s_nonseparable_%s" % (direction, "_swt" if i.do_swt else "", self.sfx))
+            F2 = self._filters2d(direction)
+            rc = fn(self._p(self.image), self._ctab, self._p(self.tmp), self.info, C.byref(F2))
+            assert rc == 0
+            return
         name, needs_filters = self._driver(direction)
         fn = getattr(lib(), "orc_%s_%s" % (name, self.sfx))
         args = [self._p(self.image), self._ctab, self._p(self.tmp), self.info]

@@ -534,6 +534,185 @@ int FN(orc_soft_thresh)(T** c, T beta, orc_info w, int do_thresh_appcoeffs, int 
     return 0;
 }
 
+/* =============================================================================================
+ * Non-separable 2-D transform (reference src/nonseparable.cu), restated sample by sample.
+ * Four hlen x hlen kernels K[0..3] = (LL, LH, HL, HH), row-major [y][x].  For the named wavelets they are the
+ * outer products of the 1-D banks (w_compute_filters, src/nonseparable.cu:32-83):
+ *   LL[y][x] = l[y] l[x],  LH[y][x] = l[y] h[x],  HL[y][x] = h[y] l[x],  HH[y][x] = h[y] h[x]
+ * so the band the reference calls H (LH: low-pass along y, high-pass along x) is what its SEPARABLE path calls V
+ * and vice versa (the "CHECKME" at :72,78): with do_separable = 0 the H and V bands come out swapped.
+ * Accumulation order: jy outer, jx inner, one FMA per tap (nvcc contracts `res += v*k`).
+ * ============================================================================================= */
+typedef struct FN(orc_filters2d) {
+    int hlen;
+    T K[4][ORC_MAX_FILTER_WIDTH * ORC_MAX_FILTER_WIDTH];
+} FN(orc_filters2d);
+
+/* outer products of a 1-D pair (l, h): w_outer + w_compute_filters, src/nonseparable.cu:16-83 */
+void FN(orc_outer_filters)(const T* l, const T* h, int hlen, FN(orc_filters2d)* out)
+{
+    out->hlen = hlen;
+    for (int i = 0; i < hlen; i++)
+        for (int j = 0; j < hlen; j++) {
+            out->K[0][i * hlen + j] = l[i] * l[j];
+            out->K[1][i * hlen + j] = l[i] * h[j];
+            out->K[2][i * hlen + j] = h[i] * l[j];
+            out->K[3][i * hlen + j] = h[i] * h[j];
+        }
+}
+
+/* w_kern_forward, src/nonseparable.cu:114-170: one decimated level, in (Nr x Nc) -> 4 bands (Nr2 x Nc2) */
+static void FN(ns_forward_level)(const T* img, T* cA, T* cH, T* cV, T* cD, int Nr, int Nc, const FN(orc_filters2d)* f)
+{
+    const int hlen = f->hlen;
+    const int c = (hlen & 1) ? hlen / 2 : hlen / 2 - 1;
+    const int Nr2 = orc_div2(Nr), Nc2 = orc_div2(Nc);
+#pragma omp parallel for schedule(static)
+    for (int gy = 0; gy < Nr2; gy++)
+        for (int gx = 0; gx < Nc2; gx++) {
+            T ra = 0, rh = 0, rv = 0, rd = 0;
+            for (int jy = 0; jy < hlen; jy++) {
+                const int iy = orc_wrap_ext(2 * gy - c + jy, Nr);
+                for (int jx = 0; jx < hlen; jx++) {
+                    const int ix = orc_wrap_ext(2 * gx - c + jx, Nc);
+                    const T v = img[(size_t)iy * Nc + ix];
+                    const int k = (hlen - 1 - jy) * hlen + (hlen - 1 - jx);
+                    ra = FMA(v, f->K[0][k], ra);
+                    rh = FMA(v, f->K[1][k], rh);
+                    rv = FMA(v, f->K[2][k], rv);
+                    rd = FMA(v, f->K[3][k], rd);
+                }
+            }
+            const size_t o = (size_t)gy * Nc2 + gx;
+            cA[o] = ra; cH[o] = rh; cV[o] = rv; cD[o] = rd;
+        }
+}
+
+/* w_kern_inverse, src/nonseparable.cu:176-226: bands (Nr x Nc) -> img (Nr2 x Nc2 = output size) */
+static void FN(ns_inverse_level)(T* img, const T* cA, const T* cH, const T* cV, const T* cD, int Nr, int Nc, int Nr2, int Nc2,
+                                 const FN(orc_filters2d)* f)
+{
+    const int hlen = f->hlen, h2 = hlen / 2;
+    const int c = h2 / 2;
+    const int shift = (h2 & 1) ? 0 : 1;
+#pragma omp parallel for schedule(static)
+    for (int oy = 0; oy < Nr2; oy++)
+        for (int ox = 0; ox < Nc2; ox++) {
+            const int gy = oy + shift, gx = ox + shift;  /* "virtual id for shift" */
+            const int offy = 1 - (gy & 1), offx = 1 - (gx & 1);
+            T ra = 0, rh = 0, rv = 0, rd = 0;
+            for (int jy = 0; jy < h2; jy++) {
+                const int iy = orc_wrap(gy / 2 - c + jy, Nr);
+                for (int jx = 0; jx < h2; jx++) {
+                    const int ix = orc_wrap(gx / 2 - c + jx, Nc);
+                    const int k = (hlen - 1 - (2 * jy + offy)) * hlen + (hlen - 1 - (2 * jx + offx));
+                    const size_t o = (size_t)iy * Nc + ix;
+                    ra = FMA(cA[o], f->K[0][k], ra);
+                    rh = FMA(cH[o], f->K[1][k], rh);
+                    rv = FMA(cV[o], f->K[2][k], rv);
+                    rd = FMA(cD[o], f->K[3][k], rd);
+                }
+            }
+            img[(size_t)oy * Nc2 + ox] = ra + rh + rv + rd;
+        }
+}
+
+/* w_forward, src/nonseparable.cu:233-258 (ping-pong of the approximation; here through tmp, result in band 0) */
+int FN(orc_forward_nonseparable)(const T* image, T** c, T* tmp, orc_info w, const FN(orc_filters2d)* f)
+{
+    int nr = w.Nr, nc = w.Nc;
+    const T* in = image;
+    T* bufs[2] = { tmp, tmp + (size_t)orc_div2(w.Nr) * orc_div2(w.Nc) };
+    for (int i = 0; i < w.nlevels; i++) {
+        T* aout = (i == w.nlevels - 1) ? c[0] : bufs[i & 1];
+        FN(ns_forward_level)(in, aout, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], nr, nc, f);
+        in = aout;
+        nr = orc_div2(nr); nc = orc_div2(nc);
+    }
+    return 0;
+}
+
+/* w_inverse, src/nonseparable.cu:261-292; `f` holds the INVERSE kernels (outer products of IL, IH) */
+int FN(orc_inverse_nonseparable)(T* image, T** c, T* tmp, orc_info w, const FN(orc_filters2d)* f)
+{
+    int tNr[64] = {0}, tNc[64] = {0};
+    tNr[0] = w.Nr; tNc[0] = w.Nc;
+    for (int i = 1; i <= w.nlevels; i++) { tNr[i] = orc_div2(tNr[i - 1]); tNc[i] = orc_div2(tNc[i - 1]); }
+    T* bufs[2] = { tmp, tmp + (size_t)tNr[1] * tNc[1] };
+    const T* a = c[0];
+    for (int i = w.nlevels - 1; i >= 0; i--) {
+        T* out = (i == 0) ? image : bufs[i & 1];
+        FN(ns_inverse_level)(out, a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], tNr[i + 1], tNc[i + 1], tNr[i], tNc[i], f);
+        a = out;
+    }
+    return 0;
+}
+
+/* w_kern_forward_swt / w_kern_inverse_swt + drivers, src/nonseparable.cu:301-452 (tap spacing 2^(level-1)) */
+static void FN(ns_swt_level)(const T* in, T* oA, T* oH, T* oV, T* oD, const T* iH, const T* iV, const T* iD, int Nr, int Nc, int level,
+                             int inverse, const FN(orc_filters2d)* f)
+{
+    const int hlen = f->hlen, fac = 1 << (level - 1);
+    const int c = (inverse ? ((hlen & 1) ? hlen / 2 : hlen / 2) : ((hlen & 1) ? hlen / 2 : hlen / 2 - 1)) * fac;
+    const int ntap = inverse ? ((hlen & 1) ? hlen : hlen) : hlen;  /* hL + hR + 1 = hlen in both directions */
+#pragma omp parallel for schedule(static)
+    for (int gy = 0; gy < Nr; gy++)
+        for (int gx = 0; gx < Nc; gx++) {
+            T ra = 0, rh = 0, rv = 0, rd = 0;
+            for (int jy = 0; jy < ntap; jy++) {
+                const int iy = orc_wrap(gy - c + fac * jy, Nr);
+                for (int jx = 0; jx < ntap; jx++) {
+                    const int ix = orc_wrap(gx - c + fac * jx, Nc);
+                    const int k = (hlen - 1 - jy) * hlen + (hlen - 1 - jx);
+                    const size_t o = (size_t)iy * Nc + ix;
+                    if (!inverse) {
+                        const T v = in[o];
+                        ra = FMA(v, f->K[0][k], ra);
+                        rh = FMA(v, f->K[1][k], rh);
+                        rv = FMA(v, f->K[2][k], rv);
+                        rd = FMA(v, f->K[3][k], rd);
+                    } else { /* res += c * k / 4  (src/nonseparable.cu:386-389: product rounded, then divided, then added) */
+                        ra += in[o] * f->K[0][k] / 4;
+                        rh += iH[o] * f->K[1][k] / 4;
+                        rv += iV[o] * f->K[2][k] / 4;
+                        rd += iD[o] * f->K[3][k] / 4;
+                    }
+                }
+            }
+            const size_t o = (size_t)gy * Nc + gx;
+            if (!inverse) { oA[o] = ra; oH[o] = rh; oV[o] = rv; oD[o] = rd; }
+            else oA[o] = ra + rh + rv + rd;
+        }
+}
+
+int FN(orc_forward_swt_nonseparable)(const T* image, T** c, T* tmp, orc_info w, const FN(orc_filters2d)* f)
+{
+    const size_t n = (size_t)w.Nr * w.Nc;
+    const T* in = image;
+    T* bufs[2] = { tmp, tmp + n };
+    for (int i = 0; i < w.nlevels; i++) {
+        T* aout = (i == w.nlevels - 1) ? c[0] : bufs[i & 1];
+        FN(ns_swt_level)(in, aout, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], 0, 0, 0, w.Nr, w.Nc, i + 1, 0, f);
+        in = aout;
+    }
+    return 0;
+}
+
+int FN(orc_inverse_swt_nonseparable)(T* image, T** c, T* tmp, orc_info w, const FN(orc_filters2d)* f)
+{
+    const size_t n = (size_t)w.Nr * w.Nc;
+    T* bufs[2] = { tmp, tmp + n };
+    const T* a = c[0];
+    for (int i = w.nlevels - 1; i >= 0; i--) {
+        T* out = (i == 0) ? image : bufs[i & 1];
+        FN(ns_swt_level)(a, out, 0, 0, 0, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], w.Nr, w.Nc, i + 1, 1, f);
+        a = out;
+    }
+    return 0;
+}
+
+
+
 /* ---- norm1: Wavelets::norm1, src/wt.cu:398-418 (sum |c| over all bands incl. A) ------------
  * Accumulated in double, returned as double; callers round to T.                                */
 double FN(orc_norm1)(T** c, orc_info w)

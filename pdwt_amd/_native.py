@@ -41,7 +41,8 @@ PLAIN_SYMBOLS = ["pdwt_device_count", "pdwt_set_device", "pdwt_get_device", "pdw
                  "pdwt_kernel_count", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set"]
 TYPED_SYMBOLS = (["compute_filters_separable", "create_coeffs_buffer", "free_coeffs_buffer", "copy_coeffs_buffer",
                   "soft_thresh", "norm1", "norm1_as_double", "hard_thresh", "proj_linf", "shrink", "group_soft_thresh",
-                  "norm2sq", "norm2sq_as_double", "add_coeffs", "circshift"] + DRIVERS + HAAR_DRIVERS)
+                  "norm2sq", "norm2sq_as_double", "add_coeffs", "circshift", "forward_nonseparable", "inverse_nonseparable",
+                  "forward_swt_nonseparable", "inverse_swt_nonseparable"] + DRIVERS + HAAR_DRIVERS)
 
 _hip = None
 _host = {}
@@ -144,6 +145,8 @@ def host(dtype):
         L.pdwt_wavelets_circshift.argtypes = [vp, ci, ci, ci]
         L.pdwt_wavelets_set_filters_forward.argtypes = [vp, C.c_char_p, C.c_uint, vp, vp]
         L.pdwt_wavelets_set_filters_inverse.argtypes = [vp, vp, vp]
+        L.pdwt_wavelets_set_filters_forward4.argtypes = [vp, C.c_char_p, C.c_uint, vp, vp, vp, vp]
+        L.pdwt_wavelets_set_filters_inverse4.argtypes = [vp, vp, vp, vp, vp]
         L.pdwt_wavelets_add_wavelet.argtypes = [vp, vp, ct]
         L.pdwt_wavelets_shifts.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
         L.pdwt_wavelets_get_image.argtypes = [vp, vp]

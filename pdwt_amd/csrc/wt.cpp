@@ -52,7 +52,15 @@ static inline pdwt_info to_pdwt(const w_info& w)
     memcpy(&p, &w, sizeof(p));
     return p;
 }
-static inline filters_t* F(void* p) { return (filters_t*)p; }
+// per-instance private state behind Wavelets::filters_: the 1-D bank first (so that F() is a plain cast), then the
+// device copies of the custom non-separable kernels (4*hlen*hlen taps each; NULL unless set_filters_* gave four filters)
+struct wstate_t {
+    filters_t f;
+    DTYPE* d_k2f;  // forward LL, LH, HL, HH
+    DTYPE* d_k2i;  // inverse
+};
+static inline filters_t* F(void* p) { return &((wstate_t*)p)->f; }
+static inline wstate_t* WS(void* p) { return (wstate_t*)p; }
 
 static void report(const char* where, int rc)
 {
@@ -100,13 +108,11 @@ Wavelets::Wavelets(DTYPE* img, int Nr, int Nc, const char* wname_, int levels, i
         puts("Ignoring the do_separable option.");
         do_separable = 1;
     }
-    if (!do_separable) {
-        // The non-separable 2D transform (reference src/nonseparable.cu) is outside the hot path this
-        // build replaces; it produces the same coefficients as the separable
-        // one for every bank of the table, so the separable kernels serve the request.
-        puts("Warning: non-separable transform requested; this build computes the (identical) separable transform.");
-        do_separable = 1;
-    }
+    // do_separable == 0 (2-D): the reference convolves with the four hlen x hlen outer products of the bank
+    // (src/nonseparable.cu:32-83).  For such tensor-product kernels that is the separable transform with the H and V
+    // bands exchanged (LH = low-pass along y x high-pass along x is what the separable path calls V, :72-78), so this
+    // build runs the separable kernels -- O(hlen) instead of O(hlen^2) per sample -- on a band table with H and V
+    // swapped (nonsep_table below).  Genuinely non-separable custom kernels: set_filters_forward with four filters.
     if (ndim != 1 && ndim != 2) {
         printf("ERROR: ndim=%d is not implemented\n", ndim);
         state = W_CREATION_ERROR;
@@ -114,8 +120,8 @@ Wavelets::Wavelets(DTYPE* img, int Nr, int Nc, const char* wname_, int levels, i
     }
 
     // filters: per-instance copy of the bank
-    filters_t* fb = (filters_t*)calloc(1, sizeof(filters_t));
-    filters_ = fb;
+    filters_ = calloc(1, sizeof(wstate_t));
+    filters_t* fb = filters_ ? F(filters_) : NULL;
     int hlen = fb ? SFX(pdwt_compute_filters_separable)(this->wname, do_swt, fb) : 0;
     if (hlen <= 0) {
         printf("ERROR: unknown wavelet name %s\n", this->wname);
@@ -171,8 +177,21 @@ Wavelets::Wavelets(const Wavelets& W)
 {
     memcpy(wname, W.wname, sizeof(wname));
     if (W.filters_) {
-        filters_ = malloc(sizeof(filters_t));
-        if (filters_) memcpy(filters_, W.filters_, sizeof(filters_t));
+        filters_ = calloc(1, sizeof(wstate_t));
+        if (filters_) {
+            *F(filters_) = *F(W.filters_);
+            const size_t nb = 4 * (size_t)winfos.hlen * winfos.hlen * sizeof(DTYPE);
+            for (int d = 0; d < 2; d++) {  // deep copy of the custom 2-D kernels
+                DTYPE* src = d ? WS(W.filters_)->d_k2i : WS(W.filters_)->d_k2f;
+                if (!src) continue;
+                DTYPE* dst = (DTYPE*)pdwt_malloc(nb);
+                if (dst && pdwt_memcpy_d2d(dst, src, nb) != PDWT_OK) {
+                    pdwt_free(dst);
+                    dst = NULL;
+                }
+                (d ? WS(filters_)->d_k2i : WS(filters_)->d_k2f) = dst;
+            }
+        }
     }
     if (!W.d_image || !W.d_coeffs || (winfos.ndims != 1 && winfos.ndims != 2)) {
         if (winfos.ndims != 1 && winfos.ndims != 2) puts("ERROR: 3D wavelets not implemented yet");
@@ -195,10 +214,28 @@ Wavelets::~Wavelets()
     if (d_image) pdwt_free(d_image);
     if (d_coeffs) SFX(pdwt_free_coeffs_buffer)(d_coeffs, to_pdwt(winfos));
     if (d_tmp) pdwt_free(d_tmp);
+    if (filters_) {
+        if (WS(filters_)->d_k2f) pdwt_free(WS(filters_)->d_k2f);
+        if (WS(filters_)->d_k2i) pdwt_free(WS(filters_)->d_k2i);
+    }
     free(filters_);
 }
 
 // ---- transforms ------------------------------------------------------------------------------------
+// Band table handed to the level drivers.  Separable request: d_coeffs itself.  Non-separable request (2-D): the same
+// bands with H and V exchanged at every level, see the constructor.
+static DTYPE** nonsep_table(const Wavelets& W, DTYPE** scratch)
+{
+    if (W.do_separable || W.winfos.ndims != 2) return W.d_coeffs;
+    scratch[0] = W.d_coeffs[0];
+    for (int l = 0; l < W.winfos.nlevels; l++) {
+        scratch[3 * l + 1] = W.d_coeffs[3 * l + 2];
+        scratch[3 * l + 2] = W.d_coeffs[3 * l + 1];
+        scratch[3 * l + 3] = W.d_coeffs[3 * l + 3];
+    }
+    return scratch;
+}
+
 void Wavelets::forward()
 {
     if (state == W_CREATION_ERROR) {
@@ -212,15 +249,20 @@ void Wavelets::forward()
     }
     const pdwt_info w = to_pdwt(winfos);
     const bool haar = (winfos.hlen == 2) && !winfos.do_swt;  // dedicated 2-tap kernels
+    DTYPE* swapped[3 * 32 + 1];
+    DTYPE** bands = nonsep_table(*this, swapped);
     int rc;
     if (winfos.ndims == 1) {
         if (haar) rc = SFX(pdwt_haar_forward1d)(d_image, d_coeffs, d_tmp, w);
         else if (!winfos.do_swt) rc = SFX(pdwt_forward_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
         else rc = SFX(pdwt_forward_swt_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
     } else {
-        if (haar) rc = SFX(pdwt_haar_forward2d)(d_image, d_coeffs, d_tmp, w);
-        else if (!winfos.do_swt) rc = SFX(pdwt_forward_separable)(d_image, d_coeffs, d_tmp, w, F(filters_));
-        else rc = SFX(pdwt_forward_swt_separable)(d_image, d_coeffs, d_tmp, w, F(filters_));
+        DTYPE* k2 = (!do_separable && filters_) ? WS(filters_)->d_k2f : NULL;  // custom non-separable kernels (nonsep.hip)
+        if (k2) rc = winfos.do_swt ? SFX(pdwt_forward_swt_nonseparable)(d_image, d_coeffs, d_tmp, w, k2)
+                                   : SFX(pdwt_forward_nonseparable)(d_image, d_coeffs, d_tmp, w, k2);
+        else if (haar) rc = SFX(pdwt_haar_forward2d)(d_image, d_coeffs, d_tmp, w);
+        else if (!winfos.do_swt) rc = SFX(pdwt_forward_separable)(d_image, bands, d_tmp, w, F(filters_));
+        else rc = SFX(pdwt_forward_swt_separable)(d_image, bands, d_tmp, w, F(filters_));
     }
     if (rc != PDWT_OK) {
         report("Wavelets::forward()", rc);
@@ -242,15 +284,25 @@ void Wavelets::inverse()
     }
     const pdwt_info w = to_pdwt(winfos);
     const bool haar = (winfos.hlen == 2) && !winfos.do_swt;
+    DTYPE* swapped[3 * 32 + 1];
+    DTYPE** bands = nonsep_table(*this, swapped);
     int rc;
     if (winfos.ndims == 1) {
         if (haar) rc = SFX(pdwt_haar_inverse1d)(d_image, d_coeffs, d_tmp, w);
         else if (!winfos.do_swt) rc = SFX(pdwt_inverse_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
         else rc = SFX(pdwt_inverse_swt_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
     } else {
-        if (haar) rc = SFX(pdwt_haar_inverse2d)(d_image, d_coeffs, d_tmp, w);
-        else if (!winfos.do_swt) rc = SFX(pdwt_inverse_separable)(d_image, d_coeffs, d_tmp, w, F(filters_));
-        else rc = SFX(pdwt_inverse_swt_separable)(d_image, d_coeffs, d_tmp, w, F(filters_));
+        DTYPE* k2 = (!do_separable && filters_) ? WS(filters_)->d_k2i : NULL;
+        if (!do_separable && filters_ && WS(filters_)->d_k2f && !k2) {
+            puts("ERROR: Wavelets::inverse(): custom non-separable forward filters were set without their inverse (set_filters_inverse)");
+            state = W_INVERSE_ERROR;
+            return;
+        }
+        if (k2) rc = winfos.do_swt ? SFX(pdwt_inverse_swt_nonseparable)(d_image, d_coeffs, d_tmp, w, k2)
+                                   : SFX(pdwt_inverse_nonseparable)(d_image, d_coeffs, d_tmp, w, k2);
+        else if (haar) rc = SFX(pdwt_haar_inverse2d)(d_image, d_coeffs, d_tmp, w);
+        else if (!winfos.do_swt) rc = SFX(pdwt_inverse_separable)(d_image, bands, d_tmp, w, F(filters_));
+        else rc = SFX(pdwt_inverse_swt_separable)(d_image, bands, d_tmp, w, F(filters_));
     }
     if (rc != PDWT_OK) {
         report("Wavelets::inverse()", rc);
@@ -336,29 +388,49 @@ DTYPE Wavelets::norm2sq()
 // Custom filter banks (src/wt.cu:560-602).  The taps become per-instance state (the reference uploads them to the
 // process-global constant memory, SURVEY B-1).  Only the separable path exists in this build: filter3/filter4 of
 // the non-separable form are rejected like the reference rejects their absence (-2).
+// upload four len x len host kernels (LL, LH, HL, HH) into one device buffer; NULL on failure
+static DTYPE* upload_k2(DTYPE* f1, DTYPE* f2, DTYPE* f3, DTYPE* f4, unsigned len)
+{
+    const size_t nb1 = (size_t)len * len * sizeof(DTYPE);
+    DTYPE* d = (DTYPE*)pdwt_malloc(4 * nb1);
+    if (!d) return NULL;
+    DTYPE* src[4] = {f1, f2, f3, f4};
+    for (int b = 0; b < 4; b++)
+        if (pdwt_memcpy_h2d((char*)d + b * nb1, src[b], nb1) != PDWT_OK) {
+            pdwt_free(d);
+            return NULL;
+        }
+    return d;
+}
+
 int Wavelets::set_filters_forward(char* filtername, uint len, DTYPE* filter1, DTYPE* filter2, DTYPE* filter3, DTYPE* filter4)
 {
-    (void)filter3;
-    (void)filter4;
     if (len > PDWT_MAX_FILTER_WIDTH) {
         printf("ERROR: Wavelets.set_filters_forward(): filter length (%d) exceeds the maximum size (%d)\n", (int)len, PDWT_MAX_FILTER_WIDTH);
         return -1;
     }
-    if (!do_separable) {
-        puts("ERROR: Wavelets.set_filters_forward(): non-separable filtering is not part of this build");
-        return -2;
-    }
-    if (!filter1 || !filter2 || len < 2) return -2;
     if (!filters_) {
-        filters_ = calloc(1, sizeof(filters_t));
+        filters_ = calloc(1, sizeof(wstate_t));
         if (!filters_) return -3;
     }
-    filters_t* f = static_cast<filters_t*>(filters_);
-    for (unsigned i = 0; i < PDWT_MAX_FILTER_WIDTH; i++) {
-        f->L[i] = (i < len) ? filter1[i] : (DTYPE)0;
-        f->H[i] = (i < len) ? filter2[i] : (DTYPE)0;
+    if (!filter1 || !filter2 || len < 1) return -2;
+    if (!do_separable) {  // four len x len kernels (w_set_filters_forward_nonseparable, src/nonseparable.cu:86-95)
+        if (filter3 == NULL || filter4 == NULL) {
+            puts("ERROR: Wavelets.set_filters_forward(): expected argument 4 and 5 for non-separable filtering");
+            return -2;
+        }
+        DTYPE* d = upload_k2(filter1, filter2, filter3, filter4, len);
+        if (!d) return -3;
+        if (WS(filters_)->d_k2f) pdwt_free(WS(filters_)->d_k2f);
+        WS(filters_)->d_k2f = d;
+    } else {  // two 1-D filters (w_set_filters_forward, src/separable.cu:56-63)
+        filters_t* f = F(filters_);
+        for (unsigned i = 0; i < PDWT_MAX_FILTER_WIDTH; i++) {
+            f->L[i] = (i < len) ? filter1[i] : (DTYPE)0;
+            f->H[i] = (i < len) ? filter2[i] : (DTYPE)0;
+        }
+        f->hlen = (int)len;
     }
-    f->hlen = (int)len;
     winfos.hlen = (int)len;
     if (filtername) {
         strncpy(wname, filtername, sizeof(wname) - 1);
@@ -370,15 +442,20 @@ int Wavelets::set_filters_forward(char* filtername, uint len, DTYPE* filter1, DT
 // the inverse filters are assumed to have the length given to set_filters_forward() (src/wt.cu:584-602)
 int Wavelets::set_filters_inverse(DTYPE* filter1, DTYPE* filter2, DTYPE* filter3, DTYPE* filter4)
 {
-    (void)filter3;
-    (void)filter4;
-    if (!do_separable) {
-        puts("ERROR: Wavelets.set_filters_inverse(): non-separable filtering is not part of this build");
-        return -2;
-    }
     if (!filter1 || !filter2 || !filters_) return -2;
-    filters_t* f = static_cast<filters_t*>(filters_);
     const int len = winfos.hlen;
+    if (!do_separable) {
+        if (filter3 == NULL || filter4 == NULL) {
+            puts("ERROR: Wavelets.set_filters_inverse(): expected argument 4 and 5 for non-separable filtering");
+            return -2;
+        }
+        DTYPE* d = upload_k2(filter1, filter2, filter3, filter4, (unsigned)len);
+        if (!d) return -3;
+        if (WS(filters_)->d_k2i) pdwt_free(WS(filters_)->d_k2i);
+        WS(filters_)->d_k2i = d;
+        return 0;
+    }
+    filters_t* f = F(filters_);
     for (int i = 0; i < PDWT_MAX_FILTER_WIDTH; i++) {
         f->IL[i] = (i < len) ? filter1[i] : (DTYPE)0;
         f->IH[i] = (i < len) ? filter2[i] : (DTYPE)0;

@@ -31,6 +31,8 @@ void pdwt_wavelets_circshift(void* h, int sr, int sc, int inplace) { W(h)->circs
 DTYPE pdwt_wavelets_norm2sq(void* h) { return W(h)->norm2sq(); }
 int pdwt_wavelets_set_filters_forward(void* h, char* name, unsigned len, DTYPE* f1, DTYPE* f2) { return W(h)->set_filters_forward(name, len, f1, f2); }
 int pdwt_wavelets_set_filters_inverse(void* h, DTYPE* f1, DTYPE* f2) { return W(h)->set_filters_inverse(f1, f2); }
+int pdwt_wavelets_set_filters_forward4(void* h, char* name, unsigned len, DTYPE* f1, DTYPE* f2, DTYPE* f3, DTYPE* f4) { return W(h)->set_filters_forward(name, len, f1, f2, f3, f4); }
+int pdwt_wavelets_set_filters_inverse4(void* h, DTYPE* f1, DTYPE* f2, DTYPE* f3, DTYPE* f4) { return W(h)->set_filters_inverse(f1, f2, f3, f4); }
 int pdwt_wavelets_add_wavelet(void* h, void* other, DTYPE alpha) { return W(h)->add_wavelet(*W(other), alpha); }
 void pdwt_wavelets_shifts(void* h, int* sr, int* sc) { *sr = W(h)->current_shift_r; *sc = W(h)->current_shift_c; }
 int pdwt_wavelets_get_image(void* h, DTYPE* out) { return W(h)->get_image(out); }

@@ -177,6 +177,19 @@ class Wavelets:
         assert a.size == b.size == self.info.hlen
         return self._L.pdwt_wavelets_set_filters_inverse(self._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
 
+    def set_filters_forward_nonseparable(self, name, k_ll, k_lh, k_hl, k_hh):
+        """Four genuinely non-separable len x len analysis kernels (do_separable=0 instances only)."""
+        ks = [np.ascontiguousarray(k, dtype=self.dtype) for k in (k_ll, k_lh, k_hl, k_hh)]
+        n = ks[0].shape[0]
+        assert all(k.shape == (n, n) for k in ks)
+        return self._L.pdwt_wavelets_set_filters_forward4(self._h, name.encode(), n, *[k.ctypes.data_as(C.c_void_p) for k in ks])
+
+    def set_filters_inverse_nonseparable(self, k_ll, k_lh, k_hl, k_hh):
+        ks = [np.ascontiguousarray(k, dtype=self.dtype) for k in (k_ll, k_lh, k_hl, k_hh)]
+        n = self.info.hlen
+        assert all(k.shape == (n, n) for k in ks)
+        return self._L.pdwt_wavelets_set_filters_inverse4(self._h, *[k.ctypes.data_as(C.c_void_p) for k in ks])
+
     def add_wavelet(self, other, alpha=1.0):
         """self += alpha * other on every band (reference Wavelets::add_wavelet)."""
         return self._L.pdwt_wavelets_add_wavelet(self._h, other._h, self._ct(alpha))

@@ -599,3 +599,55 @@ def test_zero_copy_interop_with_torch_tensors():
     W.set_image(t * 2)
     assert np.array_equal(W.get_image(), (t * 2).cpu().numpy())
     assert np.array_equal(W.image_view().numpy(), W.get_image())
+
+
+# ---- do_separable = 0 ------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [((96, 128), "db4", 3, 0, np.float32), ((63, 65), "db2", 2, 0, np.float64), ((64, 80), "db3", 2, 1, np.float64),
+                                  ((48, 64), "sym4", 2, 1, np.float32), ((2048, 2048), "db4", 2, 0, np.float32)])
+def test_nonseparable_request_named_wavelets(case):
+    """do_separable=0 with a table wavelet: the reference convolves with outer-product kernels (H and V exchanged with respect to
+    the separable path); here the separable kernels run on an exchanged band table.  Checked against the oracle's 2-D restatement."""
+    shape, wname, levels, swt, dt = case
+    x = np.random.RandomState(60).uniform(-1, 1, shape).astype(dt) * 100
+    W = pdwt_amd.Wavelets(x, wname, levels, do_separable=0, do_swt=swt)
+    S = pdwt_amd.Wavelets(x, wname, levels, do_swt=swt)
+    W.forward()
+    S.forward()
+    cw, cs = W.coeffs, S.coeffs
+    for l in range(W.info.nlevels):  # exactly the separable bands, H and V exchanged
+        assert np.array_equal(cw[3 * l + 1], cs[3 * l + 2]) and np.array_equal(cw[3 * l + 2], cs[3 * l + 1]) and np.array_equal(cw[3 * l + 3], cs[3 * l + 3])
+    if x.size <= 1 << 16:
+        O = orc.OracleWavelets(x, wname, levels, do_swt=swt, do_separable=0)
+        O.forward()
+        for k, (g, o) in enumerate(zip(cw, O.coeffs)):
+            assert band_err(g, o) <= 4 * TOL[np.dtype(dt)], (k, band_err(g, o))
+        O.inverse()
+    W.inverse()
+    assert band_err(W.get_image(), x) <= 4 * TOL[np.dtype(dt)]
+
+
+@pytest.mark.parametrize("swt", [0, 1])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_custom_nonseparable_kernels_vs_oracle(dt, swt):
+    """Four arbitrary (not outer-product) hlen x hlen kernels through set_filters_forward/inverse with four filters."""
+    rs = np.random.RandomState(61)
+    for n, shape in ((5, (40, 56)), (6, (64, 48)), (4, (33, 47))):
+        if swt and (shape[0] % 4 or shape[1] % 4):
+            continue
+        kf = [rs.randn(n, n) for _ in range(4)]
+        ki = [rs.randn(n, n) for _ in range(4)]
+        x = rs.randn(*shape).astype(dt)
+        W = pdwt_amd.Wavelets(x, "db2", 2, do_separable=0, do_swt=swt)
+        O = orc.OracleWavelets(x, "db2", 2, do_separable=0, do_swt=swt)
+        for Z in (W, O):
+            assert Z.set_filters_forward_nonseparable("custom2d", *kf) == 0
+            assert Z.set_filters_inverse_nonseparable(*ki) == 0
+            Z.forward()
+        for k, (g, o) in enumerate(zip(W.coeffs, O.coeffs)):
+            assert band_err(g, o) <= TOL[np.dtype(dt)], (n, shape, k, band_err(g, o))
+        W.inverse()
+        O.inverse()
+        assert band_err(W.get_image(), O.get_image()) <= TOL[np.dtype(dt)]
+    # the reference's argument check: four filters are mandatory for a non-separable instance
+    W = pdwt_amd.Wavelets(np.zeros((32, 32), dt), "db2", 1, do_separable=0)
+    assert W.set_filters_forward("two_only", np.ones(4), np.ones(4)) == -2

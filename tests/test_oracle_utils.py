@@ -94,3 +94,21 @@ def test_oracle_circshift_is_the_cycle_spinning_shift():
     P.circshift(3, 4, 0)  # result in tmp, image untouched
     assert np.array_equal(P.image, d["input"])
     assert np.array_equal(P.tmp[: 48 * 72].reshape(48, 72), np.roll(d["input"], (3, 4), axis=(0, 1)))
+
+
+def test_oracle_nonseparable_is_separable_with_h_and_v_exchanged():
+    """src/nonseparable.cu builds LH = outer(l, h): low-pass along y, high-pass along x -- the band the separable path calls
+    V (the CHECKME at :72-78).  The 2-D restatement therefore equals the golden (pywt) bands with H and V exchanged."""
+    for name in ("u64_db4_L3_f64", "odd63x65_db2_L2", "swt64_db3_L3"):
+        d = load_golden(name)
+        kw = dict(do_swt=1) if d["kind"] == "swt2" else {}
+        O = orc.OracleWavelets(d["input"], d["wname"], d["levels"], do_separable=0, **kw)
+        O.forward()
+        L = d["levels"]
+        assert band_err(O.get_coeff(0), d["band0"]) <= 1e-10
+        for l in range(L):
+            assert band_err(O.get_coeff(3 * l + 1), d["band%d" % (3 * l + 2)]) <= 1e-10, (name, l, "H <- V")
+            assert band_err(O.get_coeff(3 * l + 2), d["band%d" % (3 * l + 1)]) <= 1e-10, (name, l, "V <- H")
+            assert band_err(O.get_coeff(3 * l + 3), d["band%d" % (3 * l + 3)]) <= 1e-10
+        O.inverse()
+        assert band_err(O.get_image(), d["recon"]) <= 1e-10
