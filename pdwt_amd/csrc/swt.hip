@@ -10,6 +10,7 @@
 
 #include "cols_ring.hpp"
 #include "common.hpp"
+#include "swt_fused.hpp"
 
 namespace pdwt {
 
@@ -287,6 +288,22 @@ static int forward_swt(T* d_image, T** c, T* d_tmp, pdwt_info w, const typename 
     const T* in = d_image;
     const dim3 grid = swt_grid(w.Nr, w.Nc);
     for (int lev = 0; lev < w.nlevels; lev++) {
+        if constexpr (sizeof(T) == 4) {
+            // row pass + column pass in one launch (swt_fused.hip).  The approximation ping-pongs between the two halves
+            // of d_tmp (free on this path) because a single launch cannot read band 0 while it overwrites it.
+            T* aout = (lev == w.nlevels - 1) ? c[0] : ((lev & 1) ? t2 : t1);
+            const int rr = swt_fwd_fused_f32(in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], w.Nr, w.Nc, w.hlen, 1 << lev, f);
+            if (rr < 0) return rr;
+            if (rr == PDWT_OK) {
+                in = aout;
+                continue;
+            }
+            if (in != d_image && in != c[0]) {  // fell off the fused path mid-way: the two-pass kernels expect the approximation in band 0
+                rc = pdwt_memcpy_d2d(c[0], in, (size_t)w.Nr * w.Nc * sizeof(T));
+                if (rc != PDWT_OK) return rc;
+                in = c[0];
+            }
+        }
         {
             int rr = swt_rows_lds<T, false>(in, in, t1, t2, w.Nr, w.Nc, w.hlen, 1 << lev, f, K_SWT_ANA_ROWS);
             if (rr < 0) return rr;

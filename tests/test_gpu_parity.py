@@ -651,3 +651,20 @@ def test_custom_nonseparable_kernels_vs_oracle(dt, swt):
     # the reference's argument check: four filters are mandatory for a non-separable instance
     W = pdwt_amd.Wavelets(np.zeros((32, 32), dt), "db2", 1, do_separable=0)
     assert W.set_filters_forward("two_only", np.ones(4), np.ones(4)) == -2
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db7", "sym8"])
+def test_swt_fused_level_equals_two_pass(wname, monkeypatch):
+    """swt_fused.hip (row pass + column pass of a forward SWT level in one launch) is bit-identical to the two-pass kernels."""
+    rs = np.random.RandomState(70)
+    for shape, levels in (((256, 512), 3), ((192, 1280), 2), ((512, 320), 4), ((64, 2048), 1)):
+        x = rs.uniform(-50, 50, shape).astype(np.float32)
+        res = []
+        for fused in ("1", "0"):
+            monkeypatch.setenv("PDWT_SWTF", fused)
+            W = pdwt_amd.Wavelets(x, wname, levels, do_swt=1)
+            W.forward()
+            res.append((W.info.nlevels, W.coeffs))
+        assert res[0][0] == res[1][0]
+        for k, (a, b) in enumerate(zip(res[0][1], res[1][1])):
+            assert np.array_equal(a, b), (wname, shape, k)
