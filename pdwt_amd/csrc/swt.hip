@@ -340,7 +340,23 @@ static int inverse_swt(T* d_image, T** c, T* d_tmp, pdwt_info w, const typename 
     T* t1 = d_tmp;
     T* t2 = d_tmp + (size_t)w.Nr * w.Nc;
     const dim3 grid = swt_grid(w.Nr, w.Nc);
+    const T* a = c[0];  // approximation feeding level i (band 0, or a half of d_tmp after a fused level)
     for (int i = w.nlevels - 1; i >= 0; i--) {
+        if constexpr (sizeof(T) == 4) {
+            // row + column synthesis in one launch (swt_fused.hip); the approximation ping-pongs through d_tmp
+            T* out = (i == 0) ? d_image : ((i & 1) ? t2 : t1);
+            const int rr = swt_inv_fused_f32(a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], out, w.Nr, w.Nc, w.hlen, 1 << i, f);
+            if (rr < 0) return rr;
+            if (rr == PDWT_OK) {
+                a = out;
+                continue;
+            }
+            if (a != c[0]) {  // fell off the fused path mid-way: the two-pass kernels read the approximation from band 0
+                rc = pdwt_memcpy_d2d(c[0], a, (size_t)w.Nr * w.Nc * sizeof(T));
+                if (rc != PDWT_OK) return rc;
+                a = c[0];
+            }
+        }
         {
             KTimer kt(K_SWT_SYN_COLS);
             int rr = swt_syn_cols_ring<T>(c[0], c[3 * i + 1], t1, w.Nr, w.Nc, w.hlen, 1 << i, f);

@@ -6,4 +6,7 @@
 namespace pdwt {
 // in (Nr x Nc) -> cA, cH, cV, cD (Nr x Nc), tap spacing fct = 2^(level-1).  `in` must not alias an output.
 int swt_fwd_fused_f32(const float* in, float* cA, float* cH, float* cV, float* cD, int Nr, int Nc, int hlen, int fct, const Taps2<float>& f);
+// bands (Nr x Nc) -> out (Nr x Nc); taps = the inverse bank already halved (taps_inv(filt, 0.5)).  `out` must not alias an input.
+int swt_inv_fused_f32(const float* cA, const float* cH, const float* cV, const float* cD, float* out, int Nr, int Nc, int hlen, int fct,
+                      const Taps2<float>& f);
 }  // namespace pdwt
