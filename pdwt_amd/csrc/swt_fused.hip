@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256) void k_swt_fwd_fused(const float* __restrict__
 #pragma unroll
                 for (int q = 0; q < 4; q++) acc[q] = v2f{0.f, 0.f};
                 if constexpr (FSEL == 0) {
-                    const float* w0 = buf + 4 * tid;  // HLc == C*f here
+                    int woff = 4 * tid;  // HLc == C*f here; laundered per row (see k_swt_inv_fused)
+                    asm("" : "+v"(woff) : "s"(r));
+                    const float* w0 = buf + woff;
                     static_for<HLEN>([&](auto J) {
                         constexpr int j = decltype(J)::value;
                         const v4f t = *reinterpret_cast<const v4f*>(w0 + j * fct);
