@@ -279,6 +279,12 @@ def main():
                                                                avg_us=ms.value * 1e3 / n.value)
         L.pdwt_ktime_enable(0)
         L.pdwt_ktime_reset()
+        if cfg["do_swt"] and cfg["ndim"] == 2 and "swt_ana_rows" not in kernels and "swt_ana_cols" in kernels:
+            # float32 SWT levels run as ONE launch per direction (swt_fused.hip, timed under the *_cols ids): a level reads N
+            # samples and writes 4N (forward) / reads 4N and writes N (inverse)
+            import numpy as np
+            nb = 5 * cfg["Nr"] * cfg["Nc"] * np.dtype(cfg["dtype"]).itemsize * levels_eff
+            per_kernel_bytes["swt_ana_cols"] = per_kernel_bytes["swt_syn_cols"] = nb
         for d in ("fwd2d", "inv2d"):  # single-level launches cover only the levels the cascade launch did not
             if d + "_casc" in kernels and d + "_fused|casc" in per_kernel_bytes:
                 per_kernel_bytes[d + "_fused"] = per_kernel_bytes[d + "_fused|casc"]
