@@ -18,6 +18,7 @@
 
 #include "common.hpp"
 #include "cols_ring.hpp"
+#include "tapreg.hpp"
 
 namespace pdwt {
 
@@ -197,25 +198,6 @@ __global__ __launch_bounds__(256) void k_syn_cols_ring(const T* __restrict__ ca,
 // it), and an opaque barrier per group keeps the compiler from hoisting the reads back into one live set:
 // 2 v_readlane per 2*G FMAs instead of per FMA.  Each accumulator still sums its taps in ascending order.
 // -------------------------------------------------------------------------------------------------
-constexpr int kTapG = 4;  // rows per tap-major group
-
-__device__ __forceinline__ float lane_bcast(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
-__device__ __forceinline__ double lane_bcast(double v, int k)
-{
-    const long long b = __double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, k);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), k);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-template <typename T> __device__ __forceinline__ void opaque(T& v) { asm volatile("" : "+v"(v)); }
-// zero-instruction ordering point: the tap registers pass through it together with one accumulator of the previous
-// tap, so the next tap's v_readlanes cannot be scheduled above the previous tap's FMAs (hoisted together, the reads
-// need every SGPR at once and hipcc spills them straight back into VGPR lanes)
-template <typename T> __device__ __forceinline__ void tap_order(T& ta, T& tb, T (&a)[8])
-{
-    asm volatile("" : "+v"(ta), "+v"(tb), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
-}
-
 template <typename T, int HLEN, int CPL>
 __global__ __launch_bounds__(256) void k_ana_cols_ring_tr(const T* __restrict__ t, T* __restrict__ lo, T* __restrict__ hi, int Nr, int Ncw,
                                                            int RO, Taps2<T> f)

@@ -24,6 +24,7 @@
 
 #include "common.hpp"
 #include "cols_ring.hpp"
+#include "rows_tr.hpp"
 #include "dwt1d_fused.hpp"
 #include "dwt_stream.hpp"
 #include "dwt_casc.hpp"
@@ -477,6 +478,10 @@ static size_t inv_fused_lds(int hlen)
 template <typename T>
 static int launch_ana_rows(const T* in, T* lo, T* hi, int Nr, int Nc, int hlen, const Taps2<T>& f)
 {
+    if constexpr (sizeof(T) == 8) {  // long double-precision banks: register-window + tap-register kernel (rows_tr.hip)
+        const int rc = ana_rows_tr_f64(in, lo, hi, Nr, Nc, hlen, f);
+        if (rc <= 0) return rc;
+    }
     constexpr int TXO = 256;
     const size_t lds = 4 * (size_t)((2 * TXO + hlen - 2) | 1) * sizeof(T);
     dim3 grid(idiv_up(div2(Nc), TXO), idiv_up(Nr, 4));
@@ -496,6 +501,10 @@ static int launch_ana_rows(const T* in, T* lo, T* hi, int Nr, int Nc, int hlen, 
 template <typename T>
 static int launch_syn_rows(const T* a, const T* d, T* out, int Nr, int Nci, int Nco, int hlen, const Taps2<T>& f)
 {
+    if constexpr (sizeof(T) == 8) {
+        const int rc = syn_rows_tr_f64(a, d, out, Nr, Nci, Nco, hlen, f);
+        if (rc <= 0) return rc;
+    }
     constexpr int TXC = 128;
     const size_t lds = 4 * 2 * (size_t)(TXC + hlen / 2) * sizeof(T);
     dim3 grid(idiv_up(Nci, TXC), idiv_up(Nr, 4));
