@@ -673,11 +673,3 @@ def test_swt_fused_level_equals_two_pass(wname, monkeypatch):
         # the fused inverse synthesises rows before columns (the operators commute): equal within rounding
         assert band_err(res[0][2], res[1][2]) <= 2e-6
         assert band_err(res[0][2], x) <= TOL[np.dtype(np.float32)]
-    for px in ("2", "4"):  # both lane widths of the fused inverse
-        monkeypatch.setenv("PDWT_SWTF", "1")
-        monkeypatch.setenv("PDWT_SWTF_PX", px)
-        x = rs.uniform(-50, 50, (256, 1536)).astype(np.float32)
-        W = pdwt_amd.Wavelets(x, wname, 3, do_swt=1)
-        W.forward()
-        W.inverse()
-        assert band_err(W.get_image(), x) <= TOL[np.dtype(np.float32)]
