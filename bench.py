@@ -280,7 +280,7 @@ def main():
         L.pdwt_ktime_enable(0)
         L.pdwt_ktime_reset()
         if cfg["do_swt"] and cfg["ndim"] == 2 and "swt_ana_rows" not in kernels and "swt_ana_cols" in kernels:
-            # float32 SWT levels run as ONE launch per direction (swt_fused.hip, timed under the *_cols ids): a level reads N
+            # float32 SWT levels run as ONE launch per direction (swt_fused.inc, timed under the *_cols ids): a level reads N
             # samples and writes 4N (forward) / reads 4N and writes N (inverse)
             import numpy as np
             nb = 5 * cfg["Nr"] * cfg["Nc"] * np.dtype(cfg["dtype"]).itemsize * levels_eff

@@ -1,4 +1,4 @@
-// cols_ring.hpp -- register-ring column passes (cols_ring.hip).  Return PDWT_OK when launched, 1 when the
+// cols_ring.hpp -- register-ring column passes (cols_ring.inc).  Return PDWT_OK when launched, 1 when the
 // filter length has no instantiation (caller falls back to the LDS-tiled kernels), negative on error.
 #pragma once
 #include "common.hpp"

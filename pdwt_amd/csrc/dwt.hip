@@ -7,7 +7,7 @@
 // This file holds the GENERAL kernels (any size, any hlen <= 40, float and double) and the level drivers.  The
 // drivers try the specialised float32 paths first -- two levels per launch (dwt_casc.hip), one streaming launch
 // per level (dwt_stream.hip), all levels of a batched-1D row in one launch (dwt1d_fused.hip), register-ring
-// column passes (cols_ring.hip) -- and fall back to the kernels below for geometries those do not take.
+// column passes (cols_ring.inc) -- and fall back to the kernels below for geometries those do not take.
 //
 // MI355X design of the general kernels (not the reference's 16x16-thread, one-global-load-per-tap structure):
 //   * one FUSED kernel per level for 2D (row pass + column pass through LDS): every input sample is
@@ -524,7 +524,7 @@ static int launch_syn_rows(const T* a, const T* d, T* out, int Nr, int Nci, int 
 template <typename T>
 static int launch_ana_cols(const T* t1, const T* t2, T* cA, T* cH, T* cV, T* cD, int Nr, int Ncw, int hlen, const Taps2<T>& f)
 {
-    if (!tiled_cols_forced()) {  // register-ring kernels (cols_ring.hip): one launch per branch
+    if (!tiled_cols_forced()) {  // register-ring kernels (cols_ring.inc): one launch per branch
         KTimer kt(K_ANA_COLS);
         int rc = ana_cols_ring<T>(t1, cA, cH, Nr, Ncw, hlen, f);
         if (rc == PDWT_OK) rc = ana_cols_ring<T>(t2, cV, cD, Nr, Ncw, hlen, f);

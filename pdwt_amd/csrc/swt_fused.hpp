@@ -1,4 +1,4 @@
-// swt_fused.hpp -- one forward SWT level per launch (swt_fused.hip).  Returns PDWT_OK when launched, 1 when the
+// swt_fused.hpp -- one forward SWT level per launch (swt_fused.inc).  Returns PDWT_OK when launched, 1 when the
 // geometry is outside this path (caller runs the row pass + column pass kernels), < 0 on a HIP error.
 #pragma once
 #include "common.hpp"

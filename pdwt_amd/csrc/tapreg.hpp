@@ -1,7 +1,7 @@
 // tapreg.hpp -- "tap register" helpers for long filter banks (double precision: 2*hlen taps do not fit a wave's SGPRs).
 // Lane k of one VGPR holds tap k; a tap is broadcast with v_readlane right before the FMAs that use it, and an ordering
 // point keeps the reads from being hoisted together (which would need every SGPR at once and spill them straight back
-// into VGPR lanes: 2.5 v_readlane per FMA measured with the taps passed by value).  See cols_ring.hip / rows_tr.hip.
+// into VGPR lanes: 2.5 v_readlane per FMA measured with the taps passed by value).  See cols_ring.inc / rows_tr.hip.
 #pragma once
 #include "common.hpp"
 

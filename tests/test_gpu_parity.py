@@ -655,7 +655,7 @@ def test_custom_nonseparable_kernels_vs_oracle(dt, swt):
 
 @pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db7", "sym8"])
 def test_swt_fused_level_equals_two_pass(wname, monkeypatch):
-    """swt_fused.hip (row pass + column pass of a forward SWT level in one launch) is bit-identical to the two-pass kernels."""
+    """swt_fused.inc (row pass + column pass of a forward SWT level in one launch) is bit-identical to the two-pass kernels."""
     rs = np.random.RandomState(70)
     for shape, levels in (((256, 512), 3), ((192, 1280), 2), ((512, 320), 4), ((64, 2048), 1)):
         x = rs.uniform(-50, 50, shape).astype(np.float32)
