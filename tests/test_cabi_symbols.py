@@ -90,3 +90,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
                 txt = open(os.path.join(d, f), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libpdwt_oracle" not in txt and "orc_" not in txt, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/pdwt_hip.h must compile as C99 (no C++-isms, no device headers), and
+    include/wt.h with a plain host C++ compiler in both precisions (the reference header needs the CUDA toolkit)."""
+    import shutil
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    c = tmp_path / "c99.c"
+    c.write_text('#include "pdwt_hip.h"\nint main(void) { pdwt_info i; (void)i; return pdwt_device_count() < -1; }\n')
+    subprocess.check_call([shutil.which("gcc") or "gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(c)])
+    cpp = tmp_path / "w.cpp"
+    cpp.write_text('#include "wt.h"\nint main() { return sizeof(Wavelets) > 0 ? 0 : 1; }\n')
+    for flags in ([], ["-DDOUBLEPRECISION"]):
+        subprocess.check_call([shutil.which("g++") or "g++", "-std=c++11", "-Wall", "-I", inc, "-fsyntax-only", str(cpp)] + flags)
