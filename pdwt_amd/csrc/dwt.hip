@@ -576,14 +576,13 @@ static int launch_syn_cols(const T* cA, const T* cH, const T* cV, const T* cD, T
 
 // one 2D forward level: in (nr x nc) -> A,H,V,D (nr2 x nc2); t1/t2 scratch for the two-pass form
 template <typename T>
-static int level_fwd2d(const T* in, T* cA, T* cH, T* cV, T* cD, T* t1, T* t2, bool t1_is_trash, int nr, int nc, int hlen, const Taps2<T>& f)
+static int level_fwd2d(const T* in, T* cA, T* cH, T* cV, T* cD, T* t1, T* t2, size_t trash_floats, int nr, int nc, int hlen, const Taps2<T>& f)
 {
     if constexpr (sizeof(T) == 4) {  // float32 fast path: LDS-free streaming kernel (dwt_stream.hip)
         if (!force_twopass()) {
             // t1 (the two-pass scratch, sized for the FULL image) is unused on this path: it serves as the trash area of
             // the streaming kernels whenever it is big enough
-            float* trash = t1_is_trash ? (float*)t1 : nullptr;
-            const int rc = fwd2d_stream_f32(in, cA, cH, cV, cD, trash, nr, nc, hlen, f);
+            const int rc = fwd2d_stream_f32(in, cA, cH, cV, cD, (float*)t1, trash_floats, nr, nc, hlen, f);
             if (rc <= 0) return rc;
         }
     }
@@ -643,12 +642,15 @@ static int level_inv2d(const T* cA, const T* cH, const T* cV, const T* cD, T* ou
 template <typename T>
 struct Scratch {
     T *t1, *t2, *ping[2];
+    size_t trash_floats;  // floats of [t1, ping0): trash area of the streaming single-level kernels (dwt_stream.hpp)
     bool t1_is_trash;  // t1 holds >= kStreamTrashFloats floats (and 16 rows of the image): usable as the streaming kernels' trash area
     Scratch(T* tmp, int Nr, int Nc, int ndims)
     {
         t1_is_trash = (ndims == 2) && ((size_t)Nr * div2(Nc) * sizeof(T) >= kStreamTrashFloats * sizeof(float)) && Nr >= 32;
         auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
         const size_t half = up((size_t)Nr * div2(Nc));
+        // [t1, ping0) = 2*half elements are free on the streaming path: the trash area of the single-level kernels
+        trash_floats = (ndims == 2) ? 2 * half * sizeof(T) / sizeof(float) : 0;
         const size_t quarter = up((size_t)(ndims == 2 ? div2(Nr) : Nr) * div2(Nc));
         t1 = tmp;
         t2 = t1 + half;
@@ -708,7 +710,7 @@ static int forward_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typ
             }
         }
         T* aout = (lev == w.nlevels - 1) ? c[0] : s.ping[pp];
-        rc = level_fwd2d(in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], s.t1, s.t2, s.t1_is_trash, nr, nc, w.hlen, f);
+        rc = level_fwd2d(in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], s.t1, s.t2, s.trash_floats, nr, nc, w.hlen, f);
         if (rc != PDWT_OK) return rc;
         in = aout;
         pp ^= 1;

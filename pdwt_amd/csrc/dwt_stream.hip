@@ -42,7 +42,7 @@ struct FwdGeom {
 template <int HLEN, int NIN>
 __global__ __launch_bounds__(256) void k_fwd2d_stream(const float* __restrict__ in, float* __restrict__ cA, float* __restrict__ cH,
                                                        float* __restrict__ cV, float* __restrict__ cD, int Nr, int Nc, int R, int VL,
-                                                       float* __restrict__ trash, ChunkMap cm, TapsLH f)
+                                                       float* __restrict__ trash, int trash_mask, ChunkMap cm, TapsLH f)
 {
     using G = FwdGeom<HLEN, NIN>;
     using VIN = typename VecOf<NIN>::type;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_fwd2d_stream(const float* __restrict__ 
         constexpr int kAfter = 4 + 6 * (HLEN / 2 - 1);
         using VOUT = typename std::conditional<P == 2, v2f, float>::type;
         // invalid (halo / overhanging) lanes store to a private trash slot and never advance
-        float* const tr = trash + (size_t)(blockIdx.x & 255) * 1024 + (threadIdx.x >> 6) * 256 + lane * P;
+        float* const tr = trash + (size_t)(blockIdx.x & trash_mask) * 1024 + (threadIdx.x >> 6) * 256 + lane * P;
         const size_t ostep = valid ? (size_t)Nc2 : 0;
         float* pA = valid ? cA + (size_t)y0 * Nc2 + ocol : tr;
         float* pH = valid ? cH + (size_t)y0 * Nc2 + ocol : tr + 64 * P;
@@ -417,7 +417,8 @@ static int pick_rows(int nrows_total, int strips, int unit)
 #define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
 
 template <int HLEN, int NIN>
-static int launch_fwd_n(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, int nr, int nc, const Taps2<float>& f2)
+static int launch_fwd_n(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, int trash_mask, int nr, int nc,
+                        const Taps2<float>& f2)
 {
     TapsLH f;
     for (int k = 0; k < PDWT_MAX_FILTER_WIDTH; k++) f.t[k] = v2f{f2.a[k], f2.b[k]};
@@ -428,21 +429,22 @@ static int launch_fwd_n(const float* in, float* cA, float* cH, float* cV, float*
     dim3 grid;
     const ChunkMap cm = make_map(idiv_up(strips, 4), idiv_up(nr / 2, R), &grid);
     KTimer kt(K_FWD2D_FUSED);
-    hipLaunchKernelGGL((k_fwd2d_stream<HLEN, NIN>), grid, dim3(256), 0, stream(), in, cA, cH, cV, cD, nr, nc, R, VL, trash, cm, f);
+    hipLaunchKernelGGL((k_fwd2d_stream<HLEN, NIN>), grid, dim3(256), 0, stream(), in, cA, cH, cV, cD, nr, nc, R, VL, trash, trash_mask, cm, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
 // wide lanes (16-byte loads) for the big levels, narrow lanes (8-byte loads, twice the waves, half the serial
 // work per wave) once a level is too small to fill the chip with wide ones
 template <int HLEN>
-static int launch_fwd(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, int nr, int nc, const Taps2<float>& f)
+static int launch_fwd(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, int trash_mask, int nr, int nc,
+                      const Taps2<float>& f)
 {
     const long long narrow_below = env_int("PDWT_STREAM_NARROW", 2048 * 2048);
     if constexpr (HLEN > 10) {  // the wide form would need 2*HLEN row + 2*HLEN ring register pairs: narrow lanes only
-        return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, trash, nr, nc, f);
+        return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, trash, trash_mask, nr, nc, f);
     } else {
-        if ((long long)nr * nc <= narrow_below) return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, trash, nr, nc, f);
-        return launch_fwd_n<HLEN, 4>(in, cA, cH, cV, cD, trash, nr, nc, f);
+        if ((long long)nr * nc <= narrow_below) return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, trash, trash_mask, nr, nc, f);
+        return launch_fwd_n<HLEN, 4>(in, cA, cH, cV, cD, trash, trash_mask, nr, nc, f);
     }
 }
 
@@ -465,15 +467,19 @@ static int launch_inv(const float* cA, const float* cH, const float* cV, const f
 #define PDWT_STREAM_FWD_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
 #define PDWT_STREAM_INV_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
 
-int fwd2d_stream_f32(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, int nr, int nc, int hlen,
+int fwd2d_stream_f32(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, size_t trash_floats, int nr, int nc, int hlen,
                      const Taps2<float>& f)
 {
-    if (!stream_enabled() || !trash) return 1;
+    if (!stream_enabled() || !trash || trash_floats < 1024) return 1;
+    // trash slots of 1024 floats, one per workgroup modulo a power of two (any overlap is harmless: nobody reads them)
+    int slots = 1;
+    while (slots < 256 && (size_t)slots * 2 * 1024 <= trash_floats) slots *= 2;
+    const int trash_mask = slots - 1;
     if ((nr & 1) || (nc & 3) || nc < 64 || nr < 2 * hlen) return 1;
     if (!al16(in) || !al16(cA) || !al16(cH) || !al16(cV) || !al16(cD)) return 1;
     switch (hlen) {
 #define X(H) \
-    case H: return launch_fwd<H>(in, cA, cH, cV, cD, trash, nr, nc, f);
+    case H: return launch_fwd<H>(in, cA, cH, cV, cD, trash, trash_mask, nr, nc, f);
         PDWT_STREAM_FWD_HLENS(X)
 #undef X
         default: return 1;

@@ -5,9 +5,10 @@
 #include "common.hpp"
 
 namespace pdwt {
-// `trash`: >= kStreamTrashFloats floats of scratch that lane-predicated stores of halo lanes are redirected to
+// `trash`: scratch that lane-predicated stores of halo lanes are redirected to: `trash_floats` >= 1024 floats (one
+// 1024-float slot per workgroup modulo a power of two, up to 256 slots = kStreamTrashFloats)
 constexpr size_t kStreamTrashFloats = 256 * 1024;
-int fwd2d_stream_f32(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, int nr, int nc, int hlen,
+int fwd2d_stream_f32(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, size_t trash_floats, int nr, int nc, int hlen,
                      const Taps2<float>& f);
 int inv2d_stream_f32(const float* cA, const float* cH, const float* cV, const float* cD, float* out, int nri, int nci, int nro, int nco,
                      int hlen, const Taps2<float>& f);
