@@ -87,6 +87,13 @@ int pdwt_event_destroy(void* ev);
 /* Per-kernel timing: when enabled, every kernel launch of the library on this thread is bracketed
  * by HIP events; pdwt_ktime_read() synchronises and returns {launch count, total ms} for the
  * kernel `kernel_id` (PDWT_K_* below) since the last reset.  Off by default (no events recorded). */
+/* stream capture of the launches of one transform into a graph (launch-bound small transforms; no reference
+ * counterpart).  begin -> enqueue drivers as usual (nothing executes) -> end returns an executable graph. */
+int pdwt_graph_allowed(void);
+int pdwt_graph_capture_begin(void);
+int pdwt_graph_capture_end(void** exec_out);
+int pdwt_graph_launch(void* exec);
+int pdwt_graph_destroy(void* exec);
 int pdwt_ktime_enable(int on);
 int pdwt_ktime_reset(void);
 int pdwt_ktime_read(int kernel_id, int* n_launches, double* total_ms);

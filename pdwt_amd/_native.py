@@ -38,7 +38,8 @@ PLAIN_SYMBOLS = ["pdwt_device_count", "pdwt_set_device", "pdwt_get_device", "pdw
                  "pdwt_memset", "pdwt_memcpy_h2d", "pdwt_memcpy_d2h", "pdwt_memcpy_d2d", "pdwt_sync", "pdwt_get_stream",
                  "pdwt_last_error_string", "pdwt_event_create", "pdwt_event_record", "pdwt_event_sync", "pdwt_event_elapsed_ms",
                  "pdwt_event_destroy", "pdwt_ktime_enable", "pdwt_ktime_reset", "pdwt_ktime_read", "pdwt_kernel_name",
-                 "pdwt_kernel_count", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set"]
+                 "pdwt_kernel_count", "pdwt_graph_allowed", "pdwt_graph_capture_begin", "pdwt_graph_capture_end", "pdwt_graph_launch",
+                 "pdwt_graph_destroy", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set"]
 TYPED_SYMBOLS = (["compute_filters_separable", "create_coeffs_buffer", "free_coeffs_buffer", "copy_coeffs_buffer",
                   "soft_thresh", "norm1", "norm1_as_double", "hard_thresh", "proj_linf", "shrink", "group_soft_thresh",
                   "norm2sq", "norm2sq_as_double", "add_coeffs", "circshift", "forward_nonseparable", "inverse_nonseparable",

@@ -189,6 +189,48 @@ int pdwt_event_destroy(void* ev)
     return PDWT_OK;
 }
 
+// ---- launch-bound transforms: stream capture into a hipGraph ------------------------------------------------
+// A small multi-level transform is a handful of 4-5 us launches whose cost is the CPU enqueue, not the GPU (512^2 db4
+// L3: 6 launches, 24 us per pair of which < 8 us is kernel time).  The class can record the launches of one forward()
+// or inverse() once and replay them as ONE graph launch (wt.cpp, opt-in: PDWT_GRAPH=1).
+int pdwt_graph_allowed(void) { return g_kt_on ? 0 : 1; }  // per-kernel event timing and capture do not mix
+int pdwt_graph_capture_begin(void)
+{
+    PDWT_HIP_TRY(hipStreamBeginCapture(pdwt::stream(), hipStreamCaptureModeThreadLocal));
+    return PDWT_OK;
+}
+int pdwt_graph_capture_end(void** exec_out)
+{
+    if (!exec_out) return PDWT_EINVAL;
+    *exec_out = nullptr;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(pdwt::stream(), &g);
+    if (e != hipSuccess || !g) {
+        (void)hipGetLastError();
+        return PDWT_EHIP;
+    }
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess || !x) {
+        (void)hipGetLastError();
+        return PDWT_EHIP;
+    }
+    *exec_out = (void*)x;
+    return PDWT_OK;
+}
+int pdwt_graph_launch(void* exec)
+{
+    if (!exec) return PDWT_EINVAL;
+    PDWT_HIP_TRY(hipGraphLaunch((hipGraphExec_t)exec, pdwt::stream()));
+    return PDWT_OK;
+}
+int pdwt_graph_destroy(void* exec)
+{
+    if (exec) PDWT_HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)exec));
+    return PDWT_OK;
+}
+
 int pdwt_ktime_enable(int on)
 {
     g_kt_on = on != 0;

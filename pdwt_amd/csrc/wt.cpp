@@ -58,6 +58,8 @@ struct wstate_t {
     filters_t f;
     DTYPE* d_k2f;  // forward LL, LH, HL, HH
     DTYPE* d_k2i;  // inverse
+    void* graph[2];  // recorded launches of forward() / inverse() (PDWT_GRAPH=1), NULL until first use
+    int graph_off;   // capture failed once for this instance: plain launches from then on
 };
 static inline filters_t* F(void* p) { return &((wstate_t*)p)->f; }
 static inline wstate_t* WS(void* p) { return (wstate_t*)p; }
@@ -209,11 +211,13 @@ Wavelets::Wavelets(const Wavelets& W)
     }
 }
 
+static void drop_graphs(void* st);
 Wavelets::~Wavelets()
 {
     if (d_image) pdwt_free(d_image);
     if (d_coeffs) SFX(pdwt_free_coeffs_buffer)(d_coeffs, to_pdwt(winfos));
     if (d_tmp) pdwt_free(d_tmp);
+    drop_graphs(filters_);
     if (filters_) {
         if (WS(filters_)->d_k2f) pdwt_free(WS(filters_)->d_k2f);
         if (WS(filters_)->d_k2i) pdwt_free(WS(filters_)->d_k2i);
@@ -236,6 +240,47 @@ static DTYPE** nonsep_table(const Wavelets& W, DTYPE** scratch)
     return scratch;
 }
 
+// PDWT_GRAPH=1: record the launches of one forward()/inverse() of this instance once and replay them as ONE graph
+// launch.  Worth it where the transform is launch-bound (small images: 6 launches of ~4 us of CPU enqueue each for
+// 512^2 db4 L3); pointless for large ones.  Everything a recorded launch depends on is fixed for the instance's life
+// (d_image, bands, d_tmp, sizes) except the filter taps: set_filters_* drops the graphs.
+static bool graph_mode()
+{
+    static const int on = getenv("PDWT_GRAPH") ? atoi(getenv("PDWT_GRAPH")) : 0;
+    return on == 1;
+}
+static void drop_graphs(void* st)
+{
+    if (!st) return;
+    for (int d = 0; d < 2; d++)
+        if (WS(st)->graph[d]) {
+            pdwt_graph_destroy(WS(st)->graph[d]);
+            WS(st)->graph[d] = NULL;
+        }
+}
+// run `enqueue` (which only launches kernels on the library stream) through the instance's graph `dir` when possible
+template <typename F>
+static int run_graphed(void* st, int dir, bool eligible, F enqueue)
+{
+    if (!eligible || !graph_mode() || !st || WS(st)->graph_off || !pdwt_graph_allowed()) return enqueue();
+    if (!WS(st)->graph[dir]) {
+        if (pdwt_graph_capture_begin() != PDWT_OK) {
+            WS(st)->graph_off = 1;
+            return enqueue();
+        }
+        const int rc = enqueue();  // recorded, not executed
+        void* exec = NULL;
+        const int rc2 = pdwt_graph_capture_end(&exec);
+        if (rc != PDWT_OK || rc2 != PDWT_OK) {
+            if (exec) pdwt_graph_destroy(exec);
+            WS(st)->graph_off = 1;
+            return rc != PDWT_OK ? rc : enqueue();
+        }
+        WS(st)->graph[dir] = exec;
+    }
+    return pdwt_graph_launch(WS(st)->graph[dir]);
+}
+
 void Wavelets::forward()
 {
     if (state == W_CREATION_ERROR) {
@@ -251,19 +296,22 @@ void Wavelets::forward()
     const bool haar = (winfos.hlen == 2) && !winfos.do_swt;  // dedicated 2-tap kernels
     DTYPE* swapped[3 * 32 + 1];
     DTYPE** bands = nonsep_table(*this, swapped);
-    int rc;
-    if (winfos.ndims == 1) {
-        if (haar) rc = SFX(pdwt_haar_forward1d)(d_image, d_coeffs, d_tmp, w);
-        else if (!winfos.do_swt) rc = SFX(pdwt_forward_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
-        else rc = SFX(pdwt_forward_swt_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
-    } else {
-        DTYPE* k2 = (!do_separable && filters_) ? WS(filters_)->d_k2f : NULL;  // custom non-separable kernels (nonsep.hip)
-        if (k2) rc = winfos.do_swt ? SFX(pdwt_forward_swt_nonseparable)(d_image, d_coeffs, d_tmp, w, k2)
-                                   : SFX(pdwt_forward_nonseparable)(d_image, d_coeffs, d_tmp, w, k2);
-        else if (haar) rc = SFX(pdwt_haar_forward2d)(d_image, d_coeffs, d_tmp, w);
-        else if (!winfos.do_swt) rc = SFX(pdwt_forward_separable)(d_image, bands, d_tmp, w, F(filters_));
-        else rc = SFX(pdwt_forward_swt_separable)(d_image, bands, d_tmp, w, F(filters_));
-    }
+    const int rc = run_graphed(filters_, 0, true, [&]() -> int {
+        int rc;
+        if (winfos.ndims == 1) {
+            if (haar) rc = SFX(pdwt_haar_forward1d)(d_image, d_coeffs, d_tmp, w);
+            else if (!winfos.do_swt) rc = SFX(pdwt_forward_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
+            else rc = SFX(pdwt_forward_swt_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
+        } else {
+            DTYPE* k2 = (!do_separable && filters_) ? WS(filters_)->d_k2f : NULL;  // custom non-separable kernels (nonsep.hip)
+            if (k2) rc = winfos.do_swt ? SFX(pdwt_forward_swt_nonseparable)(d_image, d_coeffs, d_tmp, w, k2)
+                                       : SFX(pdwt_forward_nonseparable)(d_image, d_coeffs, d_tmp, w, k2);
+            else if (haar) rc = SFX(pdwt_haar_forward2d)(d_image, d_coeffs, d_tmp, w);
+            else if (!winfos.do_swt) rc = SFX(pdwt_forward_separable)(d_image, bands, d_tmp, w, F(filters_));
+            else rc = SFX(pdwt_forward_swt_separable)(d_image, bands, d_tmp, w, F(filters_));
+        }
+        return rc;
+    });
     if (rc != PDWT_OK) {
         report("Wavelets::forward()", rc);
         state = W_FORWARD_ERROR;
@@ -286,24 +334,27 @@ void Wavelets::inverse()
     const bool haar = (winfos.hlen == 2) && !winfos.do_swt;
     DTYPE* swapped[3 * 32 + 1];
     DTYPE** bands = nonsep_table(*this, swapped);
-    int rc;
-    if (winfos.ndims == 1) {
-        if (haar) rc = SFX(pdwt_haar_inverse1d)(d_image, d_coeffs, d_tmp, w);
-        else if (!winfos.do_swt) rc = SFX(pdwt_inverse_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
-        else rc = SFX(pdwt_inverse_swt_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
-    } else {
-        DTYPE* k2 = (!do_separable && filters_) ? WS(filters_)->d_k2i : NULL;
-        if (!do_separable && filters_ && WS(filters_)->d_k2f && !k2) {
-            puts("ERROR: Wavelets::inverse(): custom non-separable forward filters were set without their inverse (set_filters_inverse)");
-            state = W_INVERSE_ERROR;
-            return;
-        }
-        if (k2) rc = winfos.do_swt ? SFX(pdwt_inverse_swt_nonseparable)(d_image, d_coeffs, d_tmp, w, k2)
-                                   : SFX(pdwt_inverse_nonseparable)(d_image, d_coeffs, d_tmp, w, k2);
-        else if (haar) rc = SFX(pdwt_haar_inverse2d)(d_image, d_coeffs, d_tmp, w);
-        else if (!winfos.do_swt) rc = SFX(pdwt_inverse_separable)(d_image, bands, d_tmp, w, F(filters_));
-        else rc = SFX(pdwt_inverse_swt_separable)(d_image, bands, d_tmp, w, F(filters_));
+    if (winfos.ndims == 2 && !do_separable && filters_ && WS(filters_)->d_k2f && !WS(filters_)->d_k2i) {
+        puts("ERROR: Wavelets::inverse(): custom non-separable forward filters were set without their inverse (set_filters_inverse)");
+        state = W_INVERSE_ERROR;
+        return;
     }
+    const int rc = run_graphed(filters_, 1, true, [&]() -> int {
+        int rc;
+        if (winfos.ndims == 1) {
+            if (haar) rc = SFX(pdwt_haar_inverse1d)(d_image, d_coeffs, d_tmp, w);
+            else if (!winfos.do_swt) rc = SFX(pdwt_inverse_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
+            else rc = SFX(pdwt_inverse_swt_separable_1d)(d_image, d_coeffs, d_tmp, w, F(filters_));
+        } else {
+            DTYPE* k2 = (!do_separable && filters_) ? WS(filters_)->d_k2i : NULL;
+            if (k2) rc = winfos.do_swt ? SFX(pdwt_inverse_swt_nonseparable)(d_image, d_coeffs, d_tmp, w, k2)
+                                       : SFX(pdwt_inverse_nonseparable)(d_image, d_coeffs, d_tmp, w, k2);
+            else if (haar) rc = SFX(pdwt_haar_inverse2d)(d_image, d_coeffs, d_tmp, w);
+            else if (!winfos.do_swt) rc = SFX(pdwt_inverse_separable)(d_image, bands, d_tmp, w, F(filters_));
+            else rc = SFX(pdwt_inverse_swt_separable)(d_image, bands, d_tmp, w, F(filters_));
+        }
+        return rc;
+    });
     if (rc != PDWT_OK) {
         report("Wavelets::inverse()", rc);
         state = W_INVERSE_ERROR;
@@ -414,6 +465,7 @@ int Wavelets::set_filters_forward(char* filtername, uint len, DTYPE* filter1, DT
         if (!filters_) return -3;
     }
     if (!filter1 || !filter2 || len < 1) return -2;
+    drop_graphs(filters_);  // recorded launches carry the old taps
     if (!do_separable) {  // four len x len kernels (w_set_filters_forward_nonseparable, src/nonseparable.cu:86-95)
         if (filter3 == NULL || filter4 == NULL) {
             puts("ERROR: Wavelets.set_filters_forward(): expected argument 4 and 5 for non-separable filtering");
@@ -443,6 +495,7 @@ int Wavelets::set_filters_forward(char* filtername, uint len, DTYPE* filter1, DT
 int Wavelets::set_filters_inverse(DTYPE* filter1, DTYPE* filter2, DTYPE* filter3, DTYPE* filter4)
 {
     if (!filter1 || !filter2 || !filters_) return -2;
+    drop_graphs(filters_);
     const int len = winfos.hlen;
     if (!do_separable) {
         if (filter3 == NULL || filter4 == NULL) {

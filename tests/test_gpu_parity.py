@@ -4,6 +4,9 @@
 Tolerances (band-normalised max error, tests/helpers.py): 1e-5 for float32 (BASELINE.json
 north_star), 1e-10 for float64; bit-exact for the Haar path (integer indexing, exact butterflies).
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -673,3 +676,17 @@ def test_swt_fused_level_equals_two_pass(wname, monkeypatch):
         # the fused inverse synthesises rows before columns (the operators commute): equal within rounding
         assert band_err(res[0][2], res[1][2]) <= 2e-6
         assert band_err(res[0][2], x) <= TOL[np.dtype(np.float32)]
+
+
+def test_graph_replay_is_bit_identical():
+    """PDWT_GRAPH=1 (forward()/inverse() recorded once per instance, replayed as one hipGraph launch) must give the
+    same bytes as plain launches: same kernels, same arguments, same order; set_filters_* drops the recording."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for mode in ("0", "1"):
+        env = dict(os.environ, PDWT_GRAPH=mode, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "graph_check.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        digests.append([ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert digests[0] == digests[1]

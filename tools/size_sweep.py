@@ -9,6 +9,8 @@ import pdwt_amd
 wname = sys.argv[1] if len(sys.argv) > 1 else "db4"
 lev = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 L = pdwt_amd.hip()
+import os
+print("PDWT_GRAPH =", os.environ.get("PDWT_GRAPH", "0"))
 print("| size | us per fwd+inv | Mpixels/s | compulsory GB/s |")
 print("|---|---|---|---|")
 for n in (256, 512, 1024, 2048, 4096, 8192, 16384):
