@@ -36,6 +36,7 @@ struct Bands1D {
 // with the struct types the prefetch array below ended up in scratch memory.
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef double v2d_t __attribute__((ext_vector_type(2)));
+typedef float pair_f32 __attribute__((ext_vector_type(2)));
 template <typename T> struct Vec16;
 template <> struct Vec16<float> { using type = v4f_t; static constexpr int N = 4; };
 template <> struct Vec16<double> { using type = v2d_t; static constexpr int N = 2; };
@@ -179,17 +180,41 @@ __global__ __launch_bounds__(256) void k_fwd1d_fused(const T* __restrict__ in, B
                     for (int q = 0; q < NV; q++) w[k * NV + q] = t[q];
                 }
                 V vlo, vhi;
+                if constexpr (sizeof(T) == 4) {
+                    // explicit (lo, hi) pairs: one v_pk_fma_f32 per (output, tap), the sample broadcast to both
+                    // halves by op_sel and the taps travelling as (L[k], H[k]) SGPR pairs.  Left to itself hipcc
+                    // packs two OUTPUTS per instruction instead and spends ~0.7 v_mov per FMA pair assembling
+                    // (w[k], w[k+2]) operands.  Same taps in the same order, one FMA each: bit-identical.
+                    pair_f32 acc[PO];
 #pragma unroll
-                for (int q = 0; q < PO; q++) {
-                    T l = 0, h = 0;
+                    for (int q = 0; q < PO; q++) acc[q] = pair_f32{0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < HLEN; j++) {
-                        const T v = w[CA - C + 2 * q + j];
-                        l = fma_t(v, f.a[HLEN - 1 - j], l);
-                        h = fma_t(v, f.b[HLEN - 1 - j], h);
+                        const pair_f32 t = pair_f32{f.a[HLEN - 1 - j], f.b[HLEN - 1 - j]};
+#pragma unroll
+                        for (int q = 0; q < PO; q++) {
+                            const float v = w[CA - C + 2 * q + j];
+                            acc[q] = __builtin_elementwise_fma(pair_f32{v, v}, t, acc[q]);
+                        }
                     }
-                    vlo[q] = l;
-                    vhi[q] = h;
+#pragma unroll
+                    for (int q = 0; q < PO; q++) {
+                        vlo[q] = acc[q][0];
+                        vhi[q] = acc[q][1];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < PO; q++) {
+                        T l = 0, h = 0;
+#pragma unroll
+                        for (int j = 0; j < HLEN; j++) {
+                            const T v = w[CA - C + 2 * q + j];
+                            l = fma_t(v, f.a[HLEN - 1 - j], l);
+                            h = fma_t(v, f.b[HLEN - 1 - j], h);
+                        }
+                        vlo[q] = l;
+                        vhi[q] = h;
+                    }
                 }
                 if (vec_ok) {  // wave-uniform
                     *reinterpret_cast<V*>(gd + i0) = vhi;
@@ -254,18 +279,53 @@ __device__ __forceinline__ void inv1d_item(const T* a, const T* sd, int it, cons
             wd[k * NV + q] = td[q];
         }
     }
+    if constexpr (sizeof(T) == 4) {
+        // The outputs gp = 2m (even phase) and gp = 2m+1 (odd phase) read the SAME coefficients a[m+j], d[m+j] with
+        // the even / odd taps: one v_pk_fma_f32 per (coefficient, tap pair), the coefficient broadcast by op_sel --
+        // no operand assembly (hipcc's own packing spends a v_mov per two FMAs).  An unpaired output at either end
+        // of the item (SHIFT = 1) takes plain FMAs.  Same taps, same order, one FMA each, same final s1 + s2.
 #pragma unroll
-    for (int q = 0; q < PO; q++) {
-        const int gp = q + SHIFT;  // g0 = it*PO is even -> parity and halving are item-local
-        const int pl = gp >> 1, off = 1 - (gp & 1);
-        T s1 = 0, s2 = 0;
+        for (int m = 0; 2 * m < PO + SHIFT; m++) {
+            const bool has_e = 2 * m >= SHIFT, has_o = 2 * m + 1 < PO + SHIFT;  // gp = 2m / 2m+1 inside the item
+            if (has_e && has_o) {
+                pair_f32 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < H2; j++) {
-            const int k = HLEN - 1 - (2 * j + off);
-            s1 = fma_t(wa[OFF0 + pl + j], f.a[k], s1);
-            s2 = fma_t(wd[OFF0 + pl + j], f.b[k], s2);
+                for (int j = 0; j < H2; j++) {
+                    const int ke = HLEN - 2 - 2 * j, ko = HLEN - 1 - 2 * j;
+                    const float xa = wa[OFF0 + m + j], xd = wd[OFF0 + m + j];
+                    s1 = __builtin_elementwise_fma(pair_f32{xa, xa}, pair_f32{f.a[ke], f.a[ko]}, s1);
+                    s2 = __builtin_elementwise_fma(pair_f32{xd, xd}, pair_f32{f.b[ke], f.b[ko]}, s2);
+                }
+                const pair_f32 r = s1 + s2;
+                const int q = 2 * m - SHIFT;
+                res[q / NV][q % NV] = r[0];
+                res[(q + 1) / NV][(q + 1) % NV] = r[1];
+            } else {
+                const int gp = has_e ? 2 * m : 2 * m + 1, off = 1 - (gp & 1), q = gp - SHIFT;
+                float s1 = 0, s2 = 0;
+#pragma unroll
+                for (int j = 0; j < H2; j++) {
+                    const int k = HLEN - 1 - (2 * j + off);
+                    s1 = fma_t(wa[OFF0 + m + j], f.a[k], s1);
+                    s2 = fma_t(wd[OFF0 + m + j], f.b[k], s2);
+                }
+                res[q / NV][q % NV] = s1 + s2;
+            }
         }
-        res[q / NV][q % NV] = s1 + s2;
+    } else {
+#pragma unroll
+        for (int q = 0; q < PO; q++) {
+            const int gp = q + SHIFT;  // g0 = it*PO is even -> parity and halving are item-local
+            const int pl = gp >> 1, off = 1 - (gp & 1);
+            T s1 = 0, s2 = 0;
+#pragma unroll
+            for (int j = 0; j < H2; j++) {
+                const int k = HLEN - 1 - (2 * j + off);
+                s1 = fma_t(wa[OFF0 + pl + j], f.a[k], s1);
+                s2 = fma_t(wd[OFF0 + pl + j], f.b[k], s2);
+            }
+            res[q / NV][q % NV] = s1 + s2;
+        }
     }
 }
 
