@@ -169,8 +169,8 @@ def pywt_timing(cfg, Nr, Nc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)  # >= ~0.1 s of GPU work: the clocks need ~50 ms of load to settle
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -267,7 +267,7 @@ def main():
     if not args.no_roofline:
         L.pdwt_ktime_enable(1)
         L.pdwt_ktime_reset()
-        ksteps = min(args.steps, 50)
+        ksteps = min(args.steps, 200)
         for _ in range(ksteps):
             step()
         sync()

@@ -41,7 +41,7 @@ write, _ = collect(wdir, "WRITE_SIZE")
 out_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 doc = json.load(open(out_path)) if os.path.exists(out_path) else {}
 doc["source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 10 --warmup 3`; "
-                 "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the kernel's launches; summaries in profiles/r01_*_pmc_*.md")
+                 "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the kernel's launches; summaries in profiles/r01v*_pmc_*.md")
 doc[cfg] = {k: {"hbm_bytes_per_launch": (2 * fetch[k] + write.get(k, 0.0)) * 1024, "fetch_kb_raw": fetch[k], "write_kb": write.get(k, 0.0), "launches_sampled": nf[k]}
             for k in fetch}
 json.dump(doc, open(out_path, "w"), indent=1, sort_keys=True)
