@@ -690,3 +690,14 @@ def test_graph_replay_is_bit_identical():
         assert out.returncode == 0, out.stdout + out.stderr
         digests.append([ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][0])
     assert digests[0] == digests[1]
+
+
+@pytest.mark.parametrize("args", [("46400", "db4", "3"), ("46400", "sym8", "4", "float32", "1")])
+def test_images_past_2_31_elements(args):
+    """Maximum sizes: a 46400 x 46400 float32 image (2.153 G elements, 8.6 GB) generated in HBM -- level-1 details at the corners,
+    the far end of the buffers and random positions against the defining sum, and the whole-image round trip (tools/big_check.py)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "big_check.py"), *args], env=dict(os.environ, PYTHONPATH=root),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "BIG OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
