@@ -1,6 +1,7 @@
 // common.hpp -- internals shared by the HIP translation units of libpdwt_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -51,9 +52,18 @@ enum KernelId {
 struct KTimer {
     int id;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    explicit KTimer(int kernel_id);
+    bool ext = false;  // events attached to the launch itself (PDWT_LAUNCH_KT) instead of recorded around it
+    explicit KTimer(int kernel_id, bool attach_to_launch = false);
     ~KTimer();
 };
+// Launch through a KTimer constructed with attach_to_launch = true: when timing is on, the two events ride on the
+// dispatch itself (hipExtLaunchKernelGGL) and read the kernel's own start / end timestamps -- what rocprofv3 reports --
+// instead of the stream-ordered interval around it, which also contains the dispatch latency of ~2 us.
+#define PDWT_LAUNCH_KT(kt, kernel, grid, block, lds, ...)                                                                  \
+    do {                                                                                                                   \
+        if ((kt).e0 && (kt).e1) hipExtLaunchKernelGGL(kernel, grid, block, lds, pdwt::stream(), (kt).e0, (kt).e1, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, pdwt::stream(), __VA_ARGS__);                                    \
+    } while (0)
 
 // ---- size rule --------------------------------------------------------------------------------
 // ceil-half: reference w_div2, src/utils.cu:24-27

@@ -560,16 +560,16 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
     if (cpx < 1) cpx = 1;
     const CascMap cm = {cpx, strips};
     const dim3 grid((unsigned)(8 * idiv_up(cpx * strips, 4)));
-    KTimer kt(K_FWD2D_CASC);
+    KTimer kt(K_FWD2D_CASC, true);
     // row registers in flight (= prefetch distance): HLEN/2 measured best (26.2 us vs 26.8 @HLEN, 28.5 @2*HLEN for 4096^2 db4);
     // a shorter pipeline fills and drains faster, and every wave fills and drains at the same time
     const int nv = env_int("PDWT_CASC_NV", HLEN % 4 == 0 ? HLEN / 2 : HLEN);
     if (nv == 2)
-        hipLaunchKernelGGL((k_fwd2d_casc<HLEN, 2>), grid, dim3(256), 0, stream(), in, b, nr, nc, VL, trash, cm, f);
+        PDWT_LAUNCH_KT(kt, (k_fwd2d_casc<HLEN, 2>), grid, dim3(256), 0, in, b, nr, nc, VL, trash, cm, f);
     else if (nv < HLEN && HLEN % 4 == 0)
-        hipLaunchKernelGGL((k_fwd2d_casc<HLEN, (HLEN % 4 == 0 ? HLEN / 2 : HLEN)>), grid, dim3(256), 0, stream(), in, b, nr, nc, VL, trash, cm, f);
+        PDWT_LAUNCH_KT(kt, (k_fwd2d_casc<HLEN, (HLEN % 4 == 0 ? HLEN / 2 : HLEN)>), grid, dim3(256), 0, in, b, nr, nc, VL, trash, cm, f);
     else
-        hipLaunchKernelGGL((k_fwd2d_casc<HLEN, HLEN>), grid, dim3(256), 0, stream(), in, b, nr, nc, VL, trash, cm, f);
+        PDWT_LAUNCH_KT(kt, (k_fwd2d_casc<HLEN, HLEN>), grid, dim3(256), 0, in, b, nr, nc, VL, trash, cm, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -605,24 +605,24 @@ static int launch_inv_casc(const CascInvBands& b, float* out, float* trash, int 
     if (cpx < 1) cpx = 1;
     const CascMap cm = {cpx, strips};
     const dim3 grid((unsigned)(8 * idiv_up(cpx * strips, 4)));
-    KTimer kt(K_INV2D_CASC);
+    KTimer kt(K_INV2D_CASC, true);
     constexpr int H2 = HLEN / 2;
     // prefetch distance in steps: 1 measured best (28.2 us vs 29.5 @2, 31.5 @H2 for 4096^2 db4, 2048 waves)
     const int pfd = env_int("PDWT_CASC_IPFD", 1);
     bool launched = false;
     if constexpr (H2 % 2 == 0) {
         if (pfd == 2) {
-            hipLaunchKernelGGL((k_inv2d_casc<HLEN, 2>), grid, dim3(256), 0, stream(), b, out, nr, nc, VL, trash, cm, f);
+            PDWT_LAUNCH_KT(kt, (k_inv2d_casc<HLEN, 2>), grid, dim3(256), 0, b, out, nr, nc, VL, trash, cm, f);
             launched = true;
         }
     }
     if constexpr (H2 * 14 - 3 <= 63 && H2 > 2) {  // a whole ring period ahead only while vmcnt can count that far
         if (pfd >= H2 && !launched) {
-            hipLaunchKernelGGL((k_inv2d_casc<HLEN, H2>), grid, dim3(256), 0, stream(), b, out, nr, nc, VL, trash, cm, f);
+            PDWT_LAUNCH_KT(kt, (k_inv2d_casc<HLEN, H2>), grid, dim3(256), 0, b, out, nr, nc, VL, trash, cm, f);
             launched = true;
         }
     }
-    if (!launched) hipLaunchKernelGGL((k_inv2d_casc<HLEN, 1>), grid, dim3(256), 0, stream(), b, out, nr, nc, VL, trash, cm, f);
+    if (!launched) PDWT_LAUNCH_KT(kt, (k_inv2d_casc<HLEN, 1>), grid, dim3(256), 0, b, out, nr, nc, VL, trash, cm, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }

@@ -428,8 +428,8 @@ static int launch_fwd_n(const float* in, float* cA, float* cH, float* cV, float*
     const int R = pick_rows(nr / 2, strips, HLEN / 2);
     dim3 grid;
     const ChunkMap cm = make_map(idiv_up(strips, 4), idiv_up(nr / 2, R), &grid);
-    KTimer kt(K_FWD2D_FUSED);
-    hipLaunchKernelGGL((k_fwd2d_stream<HLEN, NIN>), grid, dim3(256), 0, stream(), in, cA, cH, cV, cD, nr, nc, R, VL, trash, trash_mask, cm, f);
+    KTimer kt(K_FWD2D_FUSED, true);
+    PDWT_LAUNCH_KT(kt, (k_fwd2d_stream<HLEN, NIN>), grid, dim3(256), 0, in, cA, cH, cV, cD, nr, nc, R, VL, trash, trash_mask, cm, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -457,8 +457,8 @@ static int launch_inv(const float* cA, const float* cH, const float* cV, const f
     const int RQ = pick_rows(nri, strips, InvGeom<HLEN>::H2);
     dim3 grid;
     const ChunkMap cm = make_map(idiv_up(strips, 4), idiv_up(nri, RQ), &grid);
-    KTimer kt(K_INV2D_FUSED);
-    hipLaunchKernelGGL(k_inv2d_stream<HLEN>, grid, dim3(256), 0, stream(), cA, cH, cV, cD, out, nri, nci, RQ, VL, cm, f);
+    KTimer kt(K_INV2D_FUSED, true);
+    PDWT_LAUNCH_KT(kt, k_inv2d_stream<HLEN>, grid, dim3(256), 0, cA, cH, cV, cD, out, nri, nci, RQ, VL, cm, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }

@@ -59,17 +59,17 @@ static hipEvent_t ev_get()
     return e;
 }
 
-KTimer::KTimer(int kernel_id) : id(kernel_id)
+KTimer::KTimer(int kernel_id, bool attach_to_launch) : id(kernel_id), ext(attach_to_launch)
 {
     if (!g_kt_on) return;
     e0 = ev_get();
     e1 = ev_get();
-    if (e0) (void)hipEventRecord(e0, stream());
+    if (e0 && !ext) (void)hipEventRecord(e0, stream());
 }
 KTimer::~KTimer()
 {
     if (!e0 || !e1) return;
-    (void)hipEventRecord(e1, stream());
+    if (!ext) (void)hipEventRecord(e1, stream());
     if (!g_kt) g_kt = new std::vector<KRec>();
     g_kt->push_back(KRec{id, e0, e1});
 }
