@@ -533,8 +533,8 @@ static int launch_fwd(const T* in, T** c, const pdwt_info& w, const Taps2<T>& f)
     // persistent workgroups: as many as fit the chip at once (256 CUs x LDS-limited residency), each walks rows
     const int per_cu = (int)((160 * 1024) / (lds + 512)) > 8 ? 8 : (int)((160 * 1024) / (lds + 512));
     const int grid = w.Nr < 256 * per_cu ? w.Nr : 256 * per_cu;
-    KTimer kt(K_ANA_ROWS);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, stream(), in, b, w.Nr, f);
+    KTimer kt(K_ANA_ROWS, true);
+    PDWT_LAUNCH_KT(kt, k, dim3(grid), dim3(256), lds, in, b, w.Nr, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -554,17 +554,17 @@ static int launch_inv(T* out, T** c, const pdwt_info& w, const Taps2<T>& f)
         const int n = l == 0 ? b.n[w.nlevels] : b.n[l];
         pf = (n % NVh) == 0 && n / NVh <= 256 * inv_cap(l) && ((uintptr_t)b.p[l] & 15) == 0 && n >= NVh;
     }
-    KTimer kt(K_SYN_ROWS);
+    KTimer kt(K_SYN_ROWS, true);
     if (pf) {
         auto k = k_inv1d_fused_pf<T, HLEN>;
         if (set_lds(k, lds) != PDWT_OK) return PDWT_EHIP;
         const int per_cu = (int)((160 * 1024) / (lds + 512)) > 8 ? 8 : (int)((160 * 1024) / (lds + 512));
         const int grid = w.Nr < 256 * per_cu ? w.Nr : 256 * per_cu;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, stream(), out, b, w.Nr, f);
+        PDWT_LAUNCH_KT(kt, k, dim3(grid), dim3(256), lds, out, b, w.Nr, f);
     } else {
         auto k = k_inv1d_fused<T, HLEN>;
         if (set_lds(k, lds) != PDWT_OK) return PDWT_EHIP;
-        hipLaunchKernelGGL(k, dim3(w.Nr), dim3(256), lds, stream(), out, b, f);
+        PDWT_LAUNCH_KT(kt, k, dim3(w.Nr), dim3(256), lds, out, b, f);
     }
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
