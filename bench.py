@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the 157.3 TFLOP/s FP32 vector peak of MI355X_MICROARCH.md (ridge 9.8 flop/B)
 
 # name -> (rows per GPU, cols, dtype, wavelet, levels, do_swt, ndim, extra ops, unit)
 CONFIGS = {
@@ -320,6 +321,23 @@ def main():
                         "step_compulsory_bytes": step_bytes,
                         "step_compulsory_GBps": round(step_bytes / (gpu_ms / args.steps * 1e-3) / 1e9, 1),
                         "step_frac_of_peak": round(step_bytes / (gpu_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+    if roofline is not None and cfg["dtype"] == "float64" and not cfg["do_swt"]:
+        # long double-precision banks are FP64-VALU-bound on compulsory bytes -> also report the FP64 fraction.
+        # forward FMAs per level = hlen*(2*r*c2 + 4*r2*c2) (2-D) or hlen*2*r*c2 (1-D); fwd+inv = 4x that in flop
+        hl, r, c, fma = W.info.hlen, cfg["Nr"], cfg["Nc"], 0
+        for _ in range(levels_eff):
+            c2 = (c + 1) // 2
+            if cfg["ndim"] == 2:
+                r2 = (r + 1) // 2
+                fma += hl * (2 * r * c2 + 4 * r2 * c2)
+                r = r2
+            else:
+                fma += hl * 2 * r * c2
+            c = c2
+        tf = 4.0 * fma / (gpu_ms / args.steps * 1e-3) / 1e12
+        roofline["fp64"] = {"flop_per_step": 4 * fma, "achieved": round(tf, 2), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4), "note": "whole step (threshold and norm included in the time)"}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
