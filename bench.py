@@ -167,38 +167,36 @@ def pywt_timing(cfg, Nr, Nc):
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)  # >= ~0.1 s of GPU work: the clocks need ~50 ms of load to settle
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--settle-ms", type=float, default=150.0, help="untimed load before the warm-up steps (clock settling)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
-
-    # torch first: its bundled ROCm runtime then also serves libpdwt_hip.so (one HIP runtime per process)
+def pick_dominant(cfg, kernels, per_kernel_bytes, levels_eff):
+    """Dominant kernel (largest time per step among those with an algorithmic byte count) -> (name, bytes per step)."""
     import numpy as np
-    import torch
-    import torch.distributed as dist
-    import pdwt_amd
+    if cfg["do_swt"] and cfg["ndim"] == 2 and "swt_ana_rows" not in kernels and "swt_ana_cols" in kernels:
+        # float32 SWT levels run as ONE launch per direction (swt_fused.inc, timed under the *_cols ids): a level reads N
+        # samples and writes 4N (forward) / reads 4N and writes N (inverse)
+        nb = 5 * cfg["Nr"] * cfg["Nc"] * np.dtype(cfg["dtype"]).itemsize * levels_eff
+        per_kernel_bytes["swt_ana_cols"] = per_kernel_bytes["swt_syn_cols"] = nb
+    for d in ("fwd2d", "inv2d"):
+        if d + "_casc" in kernels and d + "_fused|casc" in per_kernel_bytes:
+            # single-level launches cover only the levels the cascade launches did not; whichever single-level kernels ran
+            # (streaming / register-tile / LDS-tiled) share those levels -- the byte count goes to the one that took longest
+            rest = [k for k in (d + "_stream", d + "_small", d + "_fused") if k in kernels]
+            if rest:
+                per_kernel_bytes[max(rest, key=lambda k: kernels[k]["us_per_step"])] = per_kernel_bytes[d + "_fused|casc"]
+        elif d + "_fused" in per_kernel_bytes:
+            for k in (d + "_stream", d + "_f64"):
+                if k in kernels and d + "_fused" not in kernels:
+                    per_kernel_bytes[k] = per_kernel_bytes[d + "_fused"]
+    cand = [k for k in kernels if k in per_kernel_bytes]
+    if not cand:
+        return None, 0
+    dom = max(cand, key=lambda k: kernels[k]["us_per_step"])
+    return dom, per_kernel_bytes[dom]
 
-    cfg = CONFIGS[args.config]
-    torch.cuda.set_device(local_rank)
-    L = pdwt_amd.hip()
-    assert L.pdwt_set_device(local_rank) == 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms, cpu_seconds, do_roofline):
+    """Time `steps` steps of config `name` on this rank's GPU; returns the fields of the JSON line for it."""
+    import numpy as np
+    cfg = CONFIGS[name]
 
     def barrier():
         if world > 1:
@@ -210,9 +208,9 @@ def main():
     g.manual_seed(1234 + rank)
     img = torch.rand(cfg["Nr"], cfg["Nc"], device="cuda", dtype=tdt, generator=g) * 255.0
     torch.cuda.synchronize()
-    W = pdwt_amd.Wavelets(None, cfg["wname"], cfg["levels"], do_swt=cfg["do_swt"], ndim=cfg["ndim"], dtype=cfg["dtype"],
-                          shape=(cfg["Nr"], cfg["Nc"]), device_ptr=img.data_ptr())
-    assert W.state == pdwt_amd.W_INIT, "Wavelets creation failed"
+    W = pdwt_amd_mod().Wavelets(None, cfg["wname"], cfg["levels"], do_swt=cfg["do_swt"], ndim=cfg["ndim"], dtype=cfg["dtype"],
+                                shape=(cfg["Nr"], cfg["Nc"]), device_ptr=img.data_ptr())
+    assert W.state == pdwt_amd_mod().W_INIT, "Wavelets creation failed"
     levels_eff = W.info.nlevels
 
     if cfg["extra"]:
@@ -233,11 +231,11 @@ def main():
     # untimed: bring the box to its steady clocks first (it needs ~50-100 ms of load: 20 / 2000 timed steps of C2 gave
     # 62.4 / 59.7 us per step on one box without this), then the W warm-up steps of the contract
     t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+    while (time.perf_counter() - t_settle) * 1e3 < settle_ms:
         for _ in range(20):
             step()
         sync()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     sync()
     barrier()
@@ -245,7 +243,7 @@ def main():
     e0, e1 = L.pdwt_event_create(), L.pdwt_event_create()
     t0 = time.perf_counter()
     L.pdwt_event_record(e0)
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     L.pdwt_event_record(e1)
     sync()
@@ -257,26 +255,46 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # sanity of the timed work: one fresh round trip reproduces the input (pixels really go through)
-    rt_err = None
-    if not cfg["extra"]:
-        W.set_image(img.data_ptr(), mem_is_on_device=1)
-        step()
-        out = W.get_image()
-        ref = img.cpu().numpy()
-        rt_err = float(np.abs(out.astype(np.float64) - ref).max() / np.abs(ref).max())
+    # sanity of the timed work (untimed): pixels really go through.  Every config: one fresh forward+inverse reproduces the
+    # input.  Configs with the extra operators: norm1() against a float64 sum over the bands taken by torch on the GPU
+    # (zero-copy views), before and after the threshold, and the thresholded norm must be the smaller one.
+    sanity = {}
+    ref = img.cpu().numpy()
+    # (a separate instance: the zero-copy band views below hand out raw pointers, which switches off an instance's
+    # threshold-time norm bookkeeping -- the timed instance must stay as it was for the per-kernel pass that follows)
+    S = pdwt_amd_mod().Wavelets(None, cfg["wname"], cfg["levels"], do_swt=cfg["do_swt"], ndim=cfg["ndim"], dtype=cfg["dtype"],
+                                shape=(cfg["Nr"], cfg["Nc"]), device_ptr=img.data_ptr())
+    S.forward()
+    if cfg["extra"]:
+        def torch_norm1(X):
+            X.sync()
+            return float(sum(torch.as_tensor(X.coeff_view(k), device="cuda").abs().sum(dtype=torch.float64).item() for k in range(X.nbands)))
+        S2 = S.copy()  # thresholded through the same call sequence as the timed step, on an instance nobody took pointers of
+        S2.soft_threshold(0.5)
+        n_lib2 = S2.norm1_f64()
+        n_ref2 = torch_norm1(S2)
+        n_lib, n_ref = S.norm1_f64(), torch_norm1(S)
+        sanity["norm1_rel_err"] = abs(n_lib - n_ref) / n_ref
+        sanity["norm1_after_threshold_rel_err"] = abs(n_lib2 - n_ref2) / n_ref2
+        sanity["threshold_shrinks_norm1"] = bool(n_lib2 < n_lib)
+        del S2
+    S.inverse()
+    out = S.get_image()
+    del S
+    rt_err = float(np.abs(out.astype(np.float64) - ref).max() / np.abs(ref).max())
+    sanity["roundtrip_max_rel_err"] = rt_err
 
     pixels = cfg["Nr"] * cfg["Nc"]
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * pixels / (elapsed / args.steps) / 1e6
+    ms_per_step = elapsed / steps * 1e3
+    value = world * pixels / (elapsed / steps) / 1e6
     step_bytes, per_kernel_bytes = algorithmic_bytes(cfg, levels_eff)
 
     roofline = None
     kernels = {}
-    if not args.no_roofline:
+    if do_roofline:
         L.pdwt_ktime_enable(1)
         L.pdwt_ktime_reset()
-        ksteps = min(args.steps, 200)
+        ksteps = min(steps, 200)
         for _ in range(ksteps):
             step()
         sync()
@@ -288,39 +306,30 @@ def main():
                                                                avg_us=ms.value * 1e3 / n.value)
         L.pdwt_ktime_enable(0)
         L.pdwt_ktime_reset()
-        if cfg["do_swt"] and cfg["ndim"] == 2 and "swt_ana_rows" not in kernels and "swt_ana_cols" in kernels:
-            # float32 SWT levels run as ONE launch per direction (swt_fused.inc, timed under the *_cols ids): a level reads N
-            # samples and writes 4N (forward) / reads 4N and writes N (inverse)
-            import numpy as np
-            nb = 5 * cfg["Nr"] * cfg["Nc"] * np.dtype(cfg["dtype"]).itemsize * levels_eff
-            per_kernel_bytes["swt_ana_cols"] = per_kernel_bytes["swt_syn_cols"] = nb
-        for d in ("fwd2d", "inv2d"):  # single-level launches cover only the levels the cascade launch did not
-            if d + "_casc" in kernels and d + "_fused|casc" in per_kernel_bytes:
-                per_kernel_bytes[d + "_fused"] = per_kernel_bytes[d + "_fused|casc"]
-        cand = [k for k in kernels if k in per_kernel_bytes]
-        if cand:
-            dom = max(cand, key=lambda k: kernels[k]["us_per_step"])
-            kb = per_kernel_bytes[dom]
+        dom, kb = pick_dominant(cfg, kernels, per_kernel_bytes, levels_eff)
+        if dom:
             ach = kb / (kernels[dom]["us_per_step"] * 1e-6) / 1e9
-            # HBM bytes per launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the
-            # gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE), committed under profiles/ -- not measurable live
-            traffic, tsrc = None, None
+            # HBM bytes per launch: NOT measured in this run (PMC counters need rocprofv3 passes of their own).  The figure is
+            # the one committed under profiles/ for this kernel -- (2*FETCH_SIZE + WRITE_SIZE) per the gfx950 correction of
+            # MI355X_MICROARCH.md -- marked static with the commit it was taken at; null when the kernel has none.
+            traffic, tsrc, tcommit = None, None, None
             tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tfile):
                 try:
                     tj = json.load(open(tfile))
-                    ent = tj.get(args.config, {}).get(dom)
+                    ent = tj.get(name, {}).get(dom)
                     if ent:
-                        traffic, tsrc = ent["hbm_bytes_per_launch"], tj.get("source")
+                        traffic, tsrc, tcommit = ent["hbm_bytes_per_launch"], tj.get("source"), ent.get("commit", tj.get("commit"))
                 except Exception:
                     pass
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                        "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_static": traffic is not None,
+                        "traffic_commit": tcommit, "traffic_source": tsrc,
                         "algorithmic_bytes_per_launch": kb / kernels[dom]["launches_per_step"],
                         "avg_launch_us": round(kernels[dom]["avg_us"], 2), "launches_per_step": kernels[dom]["launches_per_step"],
                         "step_compulsory_bytes": step_bytes,
-                        "step_compulsory_GBps": round(step_bytes / (gpu_ms / args.steps * 1e-3) / 1e9, 1),
-                        "step_frac_of_peak": round(step_bytes / (gpu_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+                        "step_compulsory_GBps": round(step_bytes / (gpu_ms / steps * 1e-3) / 1e9, 1),
+                        "step_frac_of_peak": round(step_bytes / (gpu_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
 
     if roofline is not None and cfg["dtype"] == "float64" and not cfg["do_swt"]:
         # long double-precision banks are FP64-VALU-bound on compulsory bytes -> also report the FP64 fraction.
@@ -335,23 +344,100 @@ def main():
             else:
                 fma += hl * 2 * r * c2
             c = c2
-        tf = 4.0 * fma / (gpu_ms / args.steps * 1e-3) / 1e12
-        roofline["fp64"] = {"flop_per_step": 4 * fma, "achieved": round(tf, 2), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4), "note": "whole step (threshold and norm included in the time)"}
+        # transform kernels only (measured kernel time, threshold and norm excluded) and the whole step
+        t_xf = sum(v["us_per_step"] for k, v in kernels.items() if k not in ("soft_thresh", "abs_sum", "abs_sum_final", "thresh_sum")) * 1e-6
+        tf_step = 4.0 * fma / (gpu_ms / steps * 1e-3) / 1e12
+        tf_xf = 4.0 * fma / t_xf / 1e12 if t_xf > 0 else None
+        roofline["fp64"] = {"flop_per_step": 4 * fma, "achieved": round(tf_xf, 2) if tf_xf else None, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(tf_xf / FP64_VECTOR_PEAK_TFLOPS, 4) if tf_xf else None,
+                            "transform_kernels_us": round(t_xf * 1e6, 1),
+                            "whole_step_achieved": round(tf_step, 2), "whole_step_frac": round(tf_step / FP64_VECTOR_PEAK_TFLOPS, 4),
+                            "note": "achieved/frac: flops over the measured time of the transform kernels; whole_step_*: over the step (threshold and norm included)"}
+        roofline["hbm_transform_kernels"] = {"compulsory_bytes": 4 * pixels * 8, "GBps": round(4 * pixels * 8 / t_xf / 1e9, 1) if t_xf > 0 else None,
+                                             "frac": round(4 * pixels * 8 / t_xf / 1e9 / HBM_PEAK_GBPS, 4) if t_xf > 0 else None}
 
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        cpu = cpu_baseline(cfg, args.cpu_seconds)
+    if rank == 0 and world == 1 and cpu_seconds > 0:
+        cpu = cpu_baseline(cfg, cpu_seconds)
+    del W
+    return {"value": round(value, 1), "unit": cfg["unit"], "ms_per_step": round(ms_per_step, 5), "gpu_ms_per_step": round(gpu_ms / steps, 5),
+            "steps": steps, "warmup": warmup, "levels": levels_eff, "workload": cfg["desc"], "dtype": "f32" if cfg["dtype"] == "float32" else "f64",
+            "sanity": sanity, "roundtrip_max_rel_err": rt_err, "roofline": roofline, "cpu_baseline": cpu,
+            "kernels": {k: {a: round(b, 3) for a, b in v.items()} for k, v in kernels.items()}}
+
+
+_PDWT = None
+
+
+def pdwt_amd_mod():
+    global _PDWT
+    if _PDWT is None:
+        import pdwt_amd
+        _PDWT = pdwt_amd
+    return _PDWT
+
+
+# short timed runs of the other BASELINE configs appended to the headline line ("other_configs"): (steps, warmup, settle ms, cpu s)
+OTHER_RUNS = {"c3": (60, 10, 60.0, 5.0), "c4": (200, 20, 60.0, 5.0), "c5": (30, 5, 60.0, 6.0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)  # >= ~0.1 s of GPU work: the clocks need ~50 ms of load to settle
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other configs (other_configs)")
+    ap.add_argument("--settle-ms", type=float, default=150.0, help="untimed load before the warm-up steps (clock settling)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    # torch first: its bundled ROCm runtime then also serves libpdwt_hip.so (one HIP runtime per process)
+    import torch
+    import torch.distributed as dist
+    pdwt_amd = pdwt_amd_mod()
+
+    torch.cuda.set_device(local_rank)
+    L = pdwt_amd.hip()
+    assert L.pdwt_set_device(local_rank) == 0
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    cfg = CONFIGS[args.config]
+    res = run_config(args.config, args, L, torch, dist, rank, world, args.steps, args.warmup, args.settle_ms, args.cpu_seconds, not args.no_roofline)
+
+    # The other BASELINE configs, short runs in the same process (N = 1 only; the headline fields above stay those of --config)
+    others = None
+    if world == 1 and not args.no_others and args.config == "c2":
+        others = {}
+        for name, (st, wu, settle, cpu_s) in OTHER_RUNS.items():
+            try:
+                r = run_config(name, args, L, torch, dist, rank, world, st, wu, settle, cpu_s if args.cpu_seconds > 0 else 0.0, not args.no_roofline)
+                others[name] = r
+            except Exception as e:  # a failing side run must not take the headline line with it -- but it must be visible
+                others[name] = {"error": repr(e)}
+            torch.cuda.empty_cache()
 
     if rank == 0:
         line = {
             "metric": "Mpixels/s fwd+inv DWT (4096\u00b2 db4 L3)" if args.config == "c2" else "%s fwd+inv (%s)" % (cfg["unit"], args.config),
-            "value": round(value, 1), "unit": cfg["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if cfg["dtype"] == "float32" else "f64", "data": "synthetic",
-            "config": {"workload": cfg["desc"], "images_per_gpu_per_step": 1, "levels": levels_eff, "parallelism": "batch-split x%d (no data-path collective)" % world},
-            "gpu_ms_per_step": round(gpu_ms / args.steps, 5), "settle_ms": args.settle_ms, "roundtrip_max_rel_err": rt_err,
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": {k: {a: round(b, 3) for a, b in v.items()} for k, v in kernels.items()},
+            "value": res["value"], "unit": cfg["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": res["dtype"], "data": "synthetic",
+            "config": {"workload": cfg["desc"], "images_per_gpu_per_step": 1, "levels": res["levels"], "parallelism": "batch-split x%d (no data-path collective)" % world},
+            "gpu_ms_per_step": res["gpu_ms_per_step"], "settle_ms": args.settle_ms, "roundtrip_max_rel_err": res["roundtrip_max_rel_err"],
+            "sanity": res["sanity"], "roofline": res["roofline"], "cpu_baseline": res["cpu_baseline"], "kernels": res["kernels"],
+            "other_configs": others,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

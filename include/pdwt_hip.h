@@ -17,8 +17,9 @@
  *   - precision is a suffix (_f32/_f64) rather than a compile-time DTYPE macro, so one kernel
  *     library serves both libpdwt.so and libpdwtd.so (Makefile:29-39 of the reference).
  *
- * All device work is enqueued on ONE non-NULL HIP stream per device owned by the library
- * (pdwt_get_stream()); nothing synchronises with the host except the functions documented to.
+ * All device work is enqueued on ONE HIP stream per device (pdwt_get_stream(); owned by the library and
+ * ordered against the NULL stream unless pdwt_set_stream / PDWT_STREAM_NONBLOCKING say otherwise); nothing
+ * synchronises with the host except the functions documented to.
  */
 #ifndef PDWT_HIP_H
 #define PDWT_HIP_H
@@ -73,9 +74,19 @@ int pdwt_free(void* dptr);
 int pdwt_memset(void* dptr, int byte, size_t nbytes);              /* stream-ordered */
 int pdwt_memcpy_h2d(void* dst, const void* src, size_t nbytes);    /* blocking */
 int pdwt_memcpy_d2h(void* dst, const void* src, size_t nbytes);    /* blocking (syncs the stream) */
-int pdwt_memcpy_d2d(void* dst, const void* src, size_t nbytes);    /* stream-ordered */
+int pdwt_memcpy_d2d(void* dst, const void* src, size_t nbytes);    /* stream-ordered (both buffers owned by the library) */
+/* device-to-device copy FROM OR TO A BUFFER OF THE CALLER (Wavelets(d_ptr, memisonhost=0), set_image(d_ptr, 1),
+ * set_coeff(d_ptr, num, 1)): waits for the NULL stream first, copies, waits for the copy -- the blocking semantics
+ * of the reference's cudaMemcpy (src/wt.cu:121-124,433-436), whatever stream the caller's producer ran on. */
+int pdwt_memcpy_d2d_foreign(void* dst, const void* src, size_t nbytes);
 int pdwt_sync(void);                         /* wait for the library stream of the current device */
 void* pdwt_get_stream(void);                 /* the hipStream_t all launches go to (opaque) */
+/* Streams.  By default all work of a device goes to ONE stream the library creates WITHOUT hipStreamNonBlocking: it
+ * is ordered against the NULL stream in both directions (legacy default-stream semantics), so a reference program,
+ * whose own kernels run on the NULL stream, needs no extra synchronisation.  PDWT_STREAM_NONBLOCKING=1 (environment,
+ * read once) creates it non-blocking instead.  pdwt_set_stream(s, 1) makes the library enqueue on the caller's
+ * stream `s` (NULL = the NULL stream) for the current device; pdwt_set_stream(NULL, 0) returns to the library stream. */
+int pdwt_set_stream(void* user_stream, int use_it);
 const char* pdwt_last_error_string(void);    /* text of the last failing HIP call (thread-local) */
 
 /* timing helpers for bench.py: HIP events recorded on the library stream */
@@ -144,9 +155,12 @@ long long pdwt_band_size(pdwt_info info, int num, int* band_Nr, int* band_Nc);
  *   inverse_swt_separable[_1d] <- src/separable.cu:629-672
  *   haar_forward2d/inverse2d/forward1d/inverse1d <- src/haar.cu:61-119,163-221
  * ------------------------------------------------------------------------------------------- */
-/* test / tuning knobs (not part of the reference seam): key "force_twopass" = 1 makes the 2D DWT
- * drivers use the two-pass (row kernel + column kernel) form instead of the fused level kernel. */
+/* test / tuning knobs (not part of the reference seam; names and meaning in INTEGRATION.md).  Each knob is
+ * initialised ONCE from its PDWT_<NAME> environment variable and changed at run time only through
+ * pdwt_debug_set; e.g. "force_twopass" = 1 makes the 2D DWT drivers use the two-pass (row kernel + column
+ * kernel) form instead of the fused level kernels.  Unknown key: PDWT_EINVAL. */
 int pdwt_debug_set(const char* key, int value);
+int pdwt_debug_get(const char* key, int* value);
 
 /* minimum element count of the d_tmp scratch the drivers need (2*Nr*Nc as in src/wt.cu:128-130,
  * plus alignment slack for the sub-buffers carved out of it) */
@@ -199,8 +213,9 @@ int pdwt_norm1_as_double_f64(double** d_coeffs, pdwt_info info, double* out);
  *                        r = max(1 - beta/||(h,v,d[,a])||_2, 0) (0 when the norm is 0), applied to h,v,d[,a];
  *                        the approximation joins the group at the last scale only (do_thresh_appcoeffs).
  *   norm2sq           <- Wavelets::norm2sq  src/wt.cu:370-395 (3L+1 cublas nrm2): sum of c^2 over all bands.
- *                        The reference's 1-D branch adds cublas_asum (sum |c|) of the detail bands (:389);
- *                        reproduced.  Accumulated in double, rounded once.
+ *                        The reference's 1-D branch adds cublas_asum (sum |c|) of the detail bands (:389):
+ *                        FIXED, the squared l2 norm is returned (knob "norm2sq_ref1d" = 1 reproduces the reference
+ *                        value).  Accumulated in double, rounded once.
  *   add_coeffs        <- w_add_coeffs / w_add_coeffs_1d  src/common.cu:499-526 (3L+1 cublas axpy):
  *                        dst[k] += alpha*src[k] for every band (whole bands, also for odd sizes in 1-D where
  *                        the reference's Nc/2 sizing leaves the last column of each band out).

@@ -312,11 +312,13 @@ class OracleWavelets:
             for v in bands:
                 v *= res
 
-    def norm2sq(self):  # src/wt.cu:370-395 (1-D branch: asum of the details, as written there)
+    def norm2sq(self, ref_quirk_1d=False):
+        """src/wt.cu:370-395: sum of squares over all bands.  The reference's 1-D branch adds asum of the details
+        (src/wt.cu:389, a bug -- SURVEY B-4): restated only when ``ref_quirk_1d``."""
         acc = 0.0
         for k in range(len(self.shapes)):
             v = self._band(k).astype(np.float64)
-            if self.info.ndims == 1 and k > 0:
+            if ref_quirk_1d and self.info.ndims == 1 and k > 0:
                 acc += np.abs(v).sum()
             else:
                 acc += (v * v).sum()

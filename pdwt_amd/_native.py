@@ -35,11 +35,11 @@ HAAR_DRIVERS = ["haar_forward2d", "haar_inverse2d", "haar_forward1d", "haar_inve
 
 # every symbol include/pdwt_hip.h declares (checked by tests/test_cabi_symbols.py)
 PLAIN_SYMBOLS = ["pdwt_device_count", "pdwt_set_device", "pdwt_get_device", "pdwt_device_name", "pdwt_malloc", "pdwt_free",
-                 "pdwt_memset", "pdwt_memcpy_h2d", "pdwt_memcpy_d2h", "pdwt_memcpy_d2d", "pdwt_sync", "pdwt_get_stream",
+                 "pdwt_memset", "pdwt_memcpy_h2d", "pdwt_memcpy_d2h", "pdwt_memcpy_d2d", "pdwt_memcpy_d2d_foreign", "pdwt_set_stream", "pdwt_sync", "pdwt_get_stream",
                  "pdwt_last_error_string", "pdwt_event_create", "pdwt_event_record", "pdwt_event_sync", "pdwt_event_elapsed_ms",
                  "pdwt_event_destroy", "pdwt_ktime_enable", "pdwt_ktime_reset", "pdwt_ktime_read", "pdwt_kernel_name",
                  "pdwt_kernel_count", "pdwt_graph_allowed", "pdwt_graph_capture_begin", "pdwt_graph_capture_end", "pdwt_graph_launch",
-                 "pdwt_graph_destroy", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set"]
+                 "pdwt_graph_destroy", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set", "pdwt_debug_get"]
 TYPED_SYMBOLS = (["compute_filters_separable", "create_coeffs_buffer", "free_coeffs_buffer", "copy_coeffs_buffer",
                   "soft_thresh", "norm1", "norm1_as_double", "hard_thresh", "proj_linf", "shrink", "group_soft_thresh",
                   "norm2sq", "norm2sq_as_double", "add_coeffs", "circshift", "forward_nonseparable", "inverse_nonseparable",
@@ -67,7 +67,8 @@ def hip():
     L.pdwt_malloc.argtypes = [sz]
     L.pdwt_free.argtypes = [vp]
     L.pdwt_memset.argtypes = [vp, ci, sz]
-    for n in ("pdwt_memcpy_h2d", "pdwt_memcpy_d2h", "pdwt_memcpy_d2d"):
+    L.pdwt_set_stream.argtypes = [vp, ci]
+    for n in ("pdwt_memcpy_h2d", "pdwt_memcpy_d2h", "pdwt_memcpy_d2d", "pdwt_memcpy_d2d_foreign"):
         getattr(L, n).argtypes = [vp, vp, sz]
     L.pdwt_get_stream.restype = vp
     L.pdwt_last_error_string.restype = C.c_char_p
@@ -86,6 +87,7 @@ def hip():
     L.pdwt_band_size.restype = C.c_longlong
     L.pdwt_band_size.argtypes = [Info, ci, C.POINTER(ci), C.POINTER(ci)]
     L.pdwt_debug_set.argtypes = [C.c_char_p, ci]
+    L.pdwt_debug_get.argtypes = [C.c_char_p, C.POINTER(ci)]
     L.pdwt_tmp_elems.restype = sz
     L.pdwt_tmp_elems.argtypes = [Info]
     for sfx, ct, FT in (("f32", C.c_float, Filters32), ("f64", C.c_double, Filters64)):

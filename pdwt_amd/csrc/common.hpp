@@ -45,6 +45,13 @@ enum KernelId {
     K_ABS_SUM_FINAL,
     K_FWD2D_CASC,  // two levels per launch (dwt_casc.hip)
     K_INV2D_CASC,
+    K_FWD2D_STREAM,  // one streaming launch per level (dwt_stream.hip)
+    K_INV2D_STREAM,
+    K_FWD2D_SMALL,   // register-tile kernels for the small, latency-bound levels (dwt_small.hip)
+    K_INV2D_SMALL,
+    K_FWD2D_F64,     // fused row+column level kernels for long double-precision banks (dwt_f64_fused.hip)
+    K_INV2D_F64,
+    K_THRESH_SUM,    // soft threshold that also leaves sum|c| of the result behind (utils.hip)
     K_COUNT
 };
 
@@ -64,6 +71,38 @@ struct KTimer {
         if ((kt).e0 && (kt).e1) hipExtLaunchKernelGGL(kernel, grid, block, lds, pdwt::stream(), (kt).e0, (kt).e1, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kernel, grid, block, lds, pdwt::stream(), __VA_ARGS__);                                    \
     } while (0)
+
+// ---- tuning / test knobs ------------------------------------------------------------------------
+// Every PDWT_* environment knob is read ONCE (first use of the table), never on the enqueue path; tests and tuning
+// scripts change a value at run time through pdwt_debug_set("<name>", value).  Names and meaning: INTEGRATION.md.
+enum KnobId {
+    KN_FORCE_TWOPASS = 0,  // 1: 2D DWT levels as row kernel + column kernel (no fused / streaming / cascade kernels)
+    KN_TILED_COLS,         // 1: LDS-tiled column kernels even where a register-ring instantiation exists
+    KN_CASC,               // 0: one launch per level instead of the two-levels-per-launch kernels
+    KN_CASC_WAVES,         // forward cascade: waves per launch (0 = auto)
+    KN_CASC_NV,            // forward cascade: input rows in flight per wave (0 = auto)
+    KN_CASC_MIN,           // smallest input (pixels) the cascade kernels take
+    KN_CASC_IWAVES,        // inverse cascade: waves per launch (0 = auto)
+    KN_CASC_IPFD,          // inverse cascade: prefetch distance in steps
+    KN_CASC_WG,            // cascade kernels: waves stacked per workgroup with LDS ring hand-off (0 = auto, 1 = independent waves)
+    KN_STREAM,             // 0: LDS-tiled fused level kernels instead of the streaming ones
+    KN_STREAM_R,           // streaming level kernels: rows per wave (0 = auto)
+    KN_STREAM_WAVES,       // streaming level kernels: target waves per launch
+    KN_STREAM_NARROW,      // streaming forward: 8-byte lanes at or below this many pixels
+    KN_SMALL,              // 0: no register-tile kernels for the small (latency-bound) levels
+    KN_ROWS_TR,            // 0: generic row kernels for long double-precision banks
+    KN_RING_R,             // ring column kernels: forced chunk height (0 = auto)
+    KN_RING_WAVES,         // ring column kernels: waves per launch
+    KN_SWTF,               // 0: two-pass SWT instead of the fused per-level kernels
+    KN_SWTF_M,             // fused SWT forward: rows per chunk (0 = auto)
+    KN_SWTF_MI,            // fused SWT inverse: rows per chunk (0 = auto)
+    KN_F64_FUSED,
+    KN_NORM2SQ_REF1D,      // 1: norm2sq of a 1-D transform adds sum|d| of the detail bands like the reference (src/wt.cu:389) instead of sum d^2          // 0: two-pass form for long double-precision 2D levels instead of the fused row+column kernels
+    KN_COUNT
+};
+int knob(KnobId id);
+int knob_set(const char* name, int value);  // PDWT_OK / PDWT_EINVAL (unknown name)
+int knob_get(const char* name, int* value);
 
 // ---- size rule --------------------------------------------------------------------------------
 // ceil-half: reference w_div2, src/utils.cu:24-27

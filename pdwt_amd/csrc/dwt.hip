@@ -28,7 +28,6 @@
 #include "dwt1d_fused.hpp"
 #include "dwt_stream.hpp"
 #include "dwt_casc.hpp"
-#include "dwt_tail.hpp"
 
 namespace pdwt {
 
@@ -430,27 +429,8 @@ static int set_lds(K kernel, size_t bytes)
     return PDWT_OK;
 }
 
-// test/tuning knob: force the two-pass (row kernel + column kernel) form for 2D levels
-static int g_force_twopass = -1;
-static bool force_twopass()
-{
-    if (g_force_twopass < 0) {
-        const char* e = getenv("PDWT_FORCE_TWOPASS");
-        g_force_twopass = (e && e[0] == '1') ? 1 : 0;
-    }
-    return g_force_twopass == 1;
-}
-
-// test / tuning knob: use the LDS-tiled column kernels even where a register-ring instantiation exists
-static int g_tiled_cols = -1;
-static bool tiled_cols_forced()
-{
-    if (g_tiled_cols < 0) {
-        const char* e = getenv("PDWT_TILED_COLS");
-        g_tiled_cols = (e && e[0] == '1') ? 1 : 0;
-    }
-    return g_tiled_cols == 1;
-}
+static bool force_twopass() { return knob(KN_FORCE_TWOPASS) == 1; }
+static bool tiled_cols_forced() { return knob(KN_TILED_COLS) == 1; }
 
 constexpr int FTX = 64, FTY = 16;           // fused tile (outputs per band / coefficient tile)
 constexpr size_t kFusedLdsBudget = 64 * 1024;  // keep >= 2 workgroups per CU (160 KiB LDS)
@@ -716,13 +696,6 @@ static int forward_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typ
         pp ^= 1;
         nr = div2(nr);
         nc = div2(nc);
-        if constexpr (sizeof(T) == 4) {
-            // opt-in: all remaining (small, latency-bound) levels in ONE launch (dwt_tail.hip)
-            if (lev == 0 && w.nlevels >= 3 && !force_twopass()) {
-                rc = fwd2d_tail_f32(in, c, 1, w.nlevels, nr, nc, w.hlen, f);
-                if (rc <= 0) return rc;
-            }
-        }
     }
     return PDWT_OK;
 }
@@ -744,17 +717,6 @@ static int inverse_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typ
     }
     const T* a = c[0];
     int top = w.nlevels - 1;
-    if constexpr (sizeof(T) == 4) {
-        // levels nlevels-1 .. 1 (the small ones) in ONE launch -> approximation of level 0's input bands (dwt_tail.hip)
-        if (w.nlevels >= 3 && !force_twopass()) {
-            rc = inv2d_head_f32(s.ping[1], c, 1, w.nlevels, tNr[1], tNc[1], w.hlen, f);
-            if (rc < 0) return rc;
-            if (rc == PDWT_OK) {
-                a = s.ping[1];
-                top = 0;
-            }
-        }
-    }
     int pp = (a == s.ping[0]) ? 1 : 0;  // scratch buffer the next intermediate approximation goes to (never the one `a` lives in)
     for (int i = top; i >= 0; i--) {
         if constexpr (sizeof(T) == 4) {
@@ -837,30 +799,8 @@ static int inverse_separable_1d(T* d_image, T** c, T* d_tmp, pdwt_info w, const 
 using namespace pdwt;
 
 extern "C" {
-int pdwt_debug_set(const char* key, int value)
-{
-    if (key && !strcmp(key, "force_twopass")) {
-        g_force_twopass = value ? 1 : 0;
-        return PDWT_OK;
-    }
-    if (key && !strcmp(key, "tiled_cols")) {  // 1: LDS-tiled column kernels instead of the register-ring ones
-        g_tiled_cols = value ? 1 : 0;
-        return PDWT_OK;
-    }
-    if (key && !strcmp(key, "casc")) {  // 0: one launch per level instead of the two-level cascade launches
-        pdwt::casc_set_enabled(value);
-        return PDWT_OK;
-    }
-    if (key && !strcmp(key, "tail")) {  // 0: one launch per level instead of the fused small-level launches
-        tail_set_enabled(value);
-        return PDWT_OK;
-    }
-    if (key && !strcmp(key, "stream")) {  // 0: use the LDS-tiled fused kernels instead of the streaming ones
-        stream_set_enabled(value);
-        return PDWT_OK;
-    }
-    return PDWT_EINVAL;
-}
+int pdwt_debug_set(const char* key, int value) { return pdwt::knob_set(key, value); }
+int pdwt_debug_get(const char* key, int* value) { return pdwt::knob_get(key, value); }
 size_t pdwt_tmp_elems(pdwt_info w) { return 2 * (size_t)(w.Nr > 0 ? w.Nr : 0) * (size_t)(w.Nc > 0 ? w.Nc : 0) + 1024; }
 int pdwt_forward_separable_f32(float* i, float** c, float* t, pdwt_info w, const pdwt_filters_f32* f) { return forward_separable<float>(i, c, t, w, f); }
 int pdwt_forward_separable_f64(double* i, double** c, double* t, pdwt_info w, const pdwt_filters_f64* f) { return forward_separable<double>(i, c, t, w, f); }

@@ -536,13 +536,7 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
 // =================================================================================================
 #define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
 
-static int g_casc_enable = -1;
-static bool casc_enabled()
-{
-    if (g_casc_enable < 0) g_casc_enable = env_int("PDWT_CASC", 1);
-    return g_casc_enable == 1;
-}
-void casc_set_enabled(int on) { g_casc_enable = on ? 1 : 0; }
+static bool casc_enabled() { return knob(KN_CASC) == 1; }
 
 template <int HLEN>
 static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, int nr, int nc, const Taps2<float>& f2)
@@ -555,7 +549,7 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
     // chunk rows: a multiple of 8 (one band per XCD), ~PDWT_CASC_WAVES waves in total, at least 4 level-2 rows each.
     // One wave per SIMD (1024) is the optimum: every extra chunk row recomputes 3(hlen-2) input rows of halo
     // (measured 27.2 us @1024, 30.9 @2048, 35 @4096 for 4096^2 db4).
-    int cpx = env_int("PDWT_CASC_WAVES", 1024) / (8 * strips);
+    int cpx = (knob(KN_CASC_WAVES) > 0 ? knob(KN_CASC_WAVES) : 1024) / (8 * strips);
     if (cpx > nr / 4 / 4 / 8) cpx = nr / 4 / 4 / 8;
     if (cpx < 1) cpx = 1;
     const CascMap cm = {cpx, strips};
@@ -563,7 +557,7 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
     KTimer kt(K_FWD2D_CASC, true);
     // row registers in flight (= prefetch distance): HLEN/2 measured best (26.2 us vs 26.8 @HLEN, 28.5 @2*HLEN for 4096^2 db4);
     // a shorter pipeline fills and drains faster, and every wave fills and drains at the same time
-    const int nv = env_int("PDWT_CASC_NV", HLEN % 4 == 0 ? HLEN / 2 : HLEN);
+    const int nv = knob(KN_CASC_NV) > 0 ? knob(KN_CASC_NV) : (HLEN % 4 == 0 ? HLEN / 2 : HLEN);
     if (nv == 2)
         PDWT_LAUNCH_KT(kt, (k_fwd2d_casc<HLEN, 2>), grid, dim3(256), 0, in, b, nr, nc, VL, trash, cm, f);
     else if (nv < HLEN && HLEN % 4 == 0)
@@ -581,7 +575,7 @@ int fwd2d_casc_f32(const float* in, float* H1, float* V1, float* D1, float* A2, 
 {
     if (!casc_enabled() || !stream_enabled() || !trash) return 1;
     if ((nr & 3) || (nc & 3) || nc < 256 || nr < 16 * hlen) return 1;
-    if ((long long)nr * nc < (long long)env_int("PDWT_CASC_MIN", 2048 * 2048)) return 1;
+    if ((long long)nr * nc < (long long)knob(KN_CASC_MIN)) return 1;
     if (!al16(in) || !al16(H1) || !al16(V1) || !al16(D1) || !al16(A2) || !al16(H2) || !al16(V2) || !al16(D2)) return 1;
     const CascBands b = {H1, V1, D1, A2, H2, V2, D2};
     switch (hlen) {
@@ -600,7 +594,7 @@ static int launch_inv_casc(const CascInvBands& b, float* out, float* trash, int 
     const int nc1 = nc / 2;
     const int strips = idiv_up(nc1, MAXVL * 2);
     const int VL = idiv_up(nc1 / 2, strips);
-    int cpx = env_int("PDWT_CASC_IWAVES", 2048) / (8 * strips);
+    int cpx = (knob(KN_CASC_IWAVES) > 0 ? knob(KN_CASC_IWAVES) : 2048) / (8 * strips);
     if (cpx > nr / 2 / 8 / 8) cpx = nr / 2 / 8 / 8;  // at least 8 level-l coefficient rows per chunk
     if (cpx < 1) cpx = 1;
     const CascMap cm = {cpx, strips};
@@ -608,7 +602,7 @@ static int launch_inv_casc(const CascInvBands& b, float* out, float* trash, int 
     KTimer kt(K_INV2D_CASC, true);
     constexpr int H2 = HLEN / 2;
     // prefetch distance in steps: 1 measured best (28.2 us vs 29.5 @2, 31.5 @H2 for 4096^2 db4, 2048 waves)
-    const int pfd = env_int("PDWT_CASC_IPFD", 1);
+    const int pfd = knob(KN_CASC_IPFD);
     bool launched = false;
     if constexpr (H2 % 2 == 0) {
         if (pfd == 2) {
@@ -635,7 +629,7 @@ int inv2d_casc_f32(const float* A2, const float* H2, const float* V2, const floa
 {
     if (!casc_enabled() || !stream_enabled() || !trash) return 1;
     if ((nr & 3) || (nc & 3) || nc < 256 || nr < 32 * hlen) return 1;
-    if ((long long)nr * nc < (long long)env_int("PDWT_CASC_MIN", 2048 * 2048)) return 1;
+    if ((long long)nr * nc < (long long)knob(KN_CASC_MIN)) return 1;
     if (!al16(out) || !al16(H1) || !al16(V1) || !al16(D1) || !al16(A2) || !al16(H2) || !al16(V2) || !al16(D2) || !al16(trash)) return 1;
     const CascInvBands b = {A2, H2, V2, D2, H1, V1, D1};
     switch (hlen) {

@@ -13,5 +13,4 @@ int fwd2d_casc_f32(const float* in, float* H1, float* V1, float* D1, float* A2, 
 // inverse levels l+1 and l: A2,H2,V2,D2 (nr/4 x nc/4) + H1,V1,D1 (nr/2 x nc/2) -> out (nr x nc)
 int inv2d_casc_f32(const float* A2, const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1,
                    float* out, float* trash, int nr, int nc, int hlen, const Taps2<float>& f);
-void casc_set_enabled(int on);
 }  // namespace pdwt

@@ -391,21 +391,15 @@ __global__ __launch_bounds__(256) void k_inv2d_stream(const float* __restrict__ 
 // =================================================================================================
 // host dispatch
 // =================================================================================================
-static int g_stream_enable = -1;
-bool stream_enabled()
-{
-    if (g_stream_enable < 0) g_stream_enable = env_int("PDWT_STREAM", 1);
-    return g_stream_enable == 1;
-}
-void stream_set_enabled(int on) { g_stream_enable = on ? 1 : 0; }
+bool stream_enabled() { return knob(KN_STREAM) == 1; }
 
 // rows of output (forward) / coefficient rows (inverse) per wave: enough waves to fill the chip
 // (256 CUs x 4 SIMDs x a few waves), chunks tall enough to amortise the halo rows
 static int pick_rows(int nrows_total, int strips, int unit)
 {
-    int R = env_int("PDWT_STREAM_R", 0);
+    int R = knob(KN_STREAM_R);
     if (R <= 0) {
-        const long long target_waves = env_int("PDWT_STREAM_WAVES", 8192);
+        const long long target_waves = knob(KN_STREAM_WAVES);
         R = (int)(((long long)nrows_total * strips) / target_waves);
         if (R > 64) R = 64;
         if (R < 2) R = 2;
@@ -428,7 +422,7 @@ static int launch_fwd_n(const float* in, float* cA, float* cH, float* cV, float*
     const int R = pick_rows(nr / 2, strips, HLEN / 2);
     dim3 grid;
     const ChunkMap cm = make_map(idiv_up(strips, 4), idiv_up(nr / 2, R), &grid);
-    KTimer kt(K_FWD2D_FUSED, true);
+    KTimer kt(K_FWD2D_STREAM, true);
     PDWT_LAUNCH_KT(kt, (k_fwd2d_stream<HLEN, NIN>), grid, dim3(256), 0, in, cA, cH, cV, cD, nr, nc, R, VL, trash, trash_mask, cm, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
@@ -439,7 +433,7 @@ template <int HLEN>
 static int launch_fwd(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, int trash_mask, int nr, int nc,
                       const Taps2<float>& f)
 {
-    const long long narrow_below = env_int("PDWT_STREAM_NARROW", 2048 * 2048);
+    const long long narrow_below = knob(KN_STREAM_NARROW);
     if constexpr (HLEN > 10) {  // the wide form would need 2*HLEN row + 2*HLEN ring register pairs: narrow lanes only
         return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, trash, trash_mask, nr, nc, f);
     } else {
@@ -457,7 +451,7 @@ static int launch_inv(const float* cA, const float* cH, const float* cV, const f
     const int RQ = pick_rows(nri, strips, InvGeom<HLEN>::H2);
     dim3 grid;
     const ChunkMap cm = make_map(idiv_up(strips, 4), idiv_up(nri, RQ), &grid);
-    KTimer kt(K_INV2D_FUSED, true);
+    KTimer kt(K_INV2D_STREAM, true);
     PDWT_LAUNCH_KT(kt, k_inv2d_stream<HLEN>, grid, dim3(256), 0, cA, cH, cV, cD, out, nri, nci, RQ, VL, cm, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;

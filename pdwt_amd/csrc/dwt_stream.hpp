@@ -13,5 +13,4 @@ int fwd2d_stream_f32(const float* in, float* cA, float* cH, float* cV, float* cD
 int inv2d_stream_f32(const float* cA, const float* cH, const float* cV, const float* cD, float* out, int nri, int nci, int nro, int nco,
                      int hlen, const Taps2<float>& f);
 bool stream_enabled();
-void stream_set_enabled(int on);
 }  // namespace pdwt

@@ -248,7 +248,7 @@ static int launch_ana_tr(const double* in, double* lo, double* hi, int Nr, int N
 
 int ana_rows_tr_f64(const double* in, double* lo, double* hi, int Nr, int Nc, int hlen, const Taps2<double>& f)
 {
-    static const int enabled = getenv("PDWT_ROWS_TR") ? atoi(getenv("PDWT_ROWS_TR")) : 1;
+    const int enabled = knob(KN_ROWS_TR);
     if (!enabled || Nc < 2 * hlen) return 1;
     switch (hlen) {
 #define X(H) \
@@ -274,7 +274,7 @@ static int launch_syn_tr(const double* a, const double* d, double* out, int Nr, 
 
 int syn_rows_tr_f64(const double* a, const double* d, double* out, int Nr, int Nci, int Nco, int hlen, const Taps2<double>& f)
 {
-    static const int enabled = getenv("PDWT_ROWS_TR") ? atoi(getenv("PDWT_ROWS_TR")) : 1;
+    const int enabled = knob(KN_ROWS_TR);
     if (!enabled || Nci < hlen) return 1;
     switch (hlen) {
 #define X(H) \

@@ -1,6 +1,7 @@
 // runtime.hip -- device / memory / stream / event plumbing of the C-ABI (include/pdwt_hip.h).
 // Replaces the bare CUDA runtime calls of the reference's class (src/wt.cu:117-130,421-468,543-549).
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -18,21 +19,83 @@ void set_last_error(hipError_t e, const char* what, const char* file, int line)
     (void)hipGetLastError();  // clear the sticky error
 }
 
-// one non-blocking stream per device, created on first use
+// One stream per device, created on first use.  It is a BLOCKING stream (hipStreamDefault): it keeps the legacy
+// ordering against the NULL stream in both directions, which is what a program written for the reference relies on
+// (the reference runs everything on the NULL stream, src/wt.cu: bare kernel launches and cudaMemcpy) -- its own
+// NULL-stream kernels that fill an image before set_image(..., 1) or read d_image / d_coeffs after forward() are
+// ordered without any call.  PDWT_STREAM_NONBLOCKING=1 opts out (the caller then orders with pdwt_sync / events);
+// pdwt_set_stream() makes the library enqueue on a stream of the caller instead (e.g. torch's current stream).
 static std::mutex g_mu;
 static hipStream_t g_streams[64] = {};
+static hipStream_t g_user_streams[64] = {};
+static bool g_user_set[64] = {};
 
 hipStream_t stream()
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (g_user_set[dev]) return g_user_streams[dev];
     if (!g_streams[dev]) {
-        if (hipStreamCreateWithFlags(&g_streams[dev], hipStreamNonBlocking) != hipSuccess) {
+        static const bool nonblocking = getenv("PDWT_STREAM_NONBLOCKING") && atoi(getenv("PDWT_STREAM_NONBLOCKING")) == 1;
+        if (hipStreamCreateWithFlags(&g_streams[dev], nonblocking ? hipStreamNonBlocking : hipStreamDefault) != hipSuccess) {
             g_streams[dev] = nullptr;
         }
     }
     return g_streams[dev];
+}
+
+// ---- knobs: environment read once, pdwt_debug_set at run time ---------------------------------------
+struct KnobDef { const char* name; const char* env; int dflt; };
+static const KnobDef g_knob_defs[KN_COUNT] = {
+    {"force_twopass", "PDWT_FORCE_TWOPASS", 0}, {"tiled_cols", "PDWT_TILED_COLS", 0},
+    {"casc", "PDWT_CASC", 1}, {"casc_waves", "PDWT_CASC_WAVES", 0}, {"casc_nv", "PDWT_CASC_NV", 0},
+    {"casc_min", "PDWT_CASC_MIN", 2048 * 2048}, {"casc_iwaves", "PDWT_CASC_IWAVES", 0}, {"casc_ipfd", "PDWT_CASC_IPFD", 1},
+    {"casc_wg", "PDWT_CASC_WG", 0},
+    {"stream", "PDWT_STREAM", 1}, {"stream_r", "PDWT_STREAM_R", 0}, {"stream_waves", "PDWT_STREAM_WAVES", 8192},
+    {"stream_narrow", "PDWT_STREAM_NARROW", 2048 * 2048}, {"small", "PDWT_SMALL", 1},
+    {"rows_tr", "PDWT_ROWS_TR", 1}, {"ring_r", "PDWT_RING_R", 0}, {"ring_waves", "PDWT_RING_WAVES", 4096},
+    {"swtf", "PDWT_SWTF", 1}, {"swtf_m", "PDWT_SWTF_M", 0}, {"swtf_mi", "PDWT_SWTF_MI", 0},
+    {"f64_fused", "PDWT_F64_FUSED", 1}, {"norm2sq_ref1d", "PDWT_NORM2SQ_REF1D", 0},
+};
+static int g_knob_vals[KN_COUNT];
+static std::once_flag g_knob_once;
+static void knob_init()
+{
+    for (int i = 0; i < KN_COUNT; i++) {
+        const char* e = getenv(g_knob_defs[i].env);
+        g_knob_vals[i] = (e && *e) ? atoi(e) : g_knob_defs[i].dflt;
+    }
+}
+int knob(KnobId id)
+{
+    std::call_once(g_knob_once, knob_init);
+    return g_knob_vals[id];
+}
+int knob_set(const char* name, int value)
+{
+    std::call_once(g_knob_once, knob_init);
+    if (!name) return PDWT_EINVAL;
+    for (int i = 0; i < KN_COUNT; i++) {
+        if (!strcmp(name, g_knob_defs[i].name)) {
+            g_knob_vals[i] = value;
+            return PDWT_OK;
+        }
+    }
+    return PDWT_EINVAL;
+}
+
+int knob_get(const char* name, int* value)
+{
+    std::call_once(g_knob_once, knob_init);
+    if (!name || !value) return PDWT_EINVAL;
+    for (int i = 0; i < KN_COUNT; i++) {
+        if (!strcmp(name, g_knob_defs[i].name)) {
+            *value = g_knob_vals[i];
+            return PDWT_OK;
+        }
+    }
+    return PDWT_EINVAL;
 }
 
 // ---- per-kernel timing ---------------------------------------------------------------------
@@ -40,7 +103,7 @@ static const char* const g_knames[K_COUNT] = {
     "fwd2d_fused", "inv2d_fused", "ana_rows", "ana_cols", "syn_cols", "syn_rows",
     "swt_ana_rows", "swt_ana_cols", "swt_syn_cols", "swt_syn_rows",
     "haar2d_fwd", "haar2d_inv", "haar1d_fwd", "haar1d_inv", "soft_thresh", "abs_sum", "abs_sum_final",
-    "fwd2d_casc", "inv2d_casc",
+    "fwd2d_casc", "inv2d_casc", "fwd2d_stream", "inv2d_stream", "fwd2d_small", "inv2d_small", "fwd2d_f64", "inv2d_f64", "thresh_sum",
 };
 struct KRec { int id; hipEvent_t e0, e1; };
 static thread_local bool g_kt_on = false;
@@ -153,12 +216,34 @@ int pdwt_memcpy_d2d(void* dst, const void* src, size_t nbytes)
     PDWT_HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, stream()));
     return PDWT_OK;
 }
+int pdwt_memcpy_d2d_foreign(void* dst, const void* src, size_t nbytes)
+{
+    if (!nbytes) return PDWT_OK;
+    // the producer of `src` is unknown: wait for the NULL stream (and every blocking stream with it) first, copy on the
+    // library stream, and wait for the copy so that the caller may reuse or free `src` at once
+    PDWT_HIP_TRY(hipStreamSynchronize(nullptr));
+    PDWT_HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, stream()));
+    PDWT_HIP_TRY(hipStreamSynchronize(stream()));
+    return PDWT_OK;
+}
 int pdwt_sync(void)
 {
     PDWT_HIP_TRY(hipStreamSynchronize(stream()));
     return PDWT_OK;
 }
 void* pdwt_get_stream(void) { return (void*)stream(); }
+int pdwt_set_stream(void* user_stream, int use_it)
+{
+    int dev = 0;
+    PDWT_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return PDWT_EINVAL;
+    // whatever is still queued on the stream used so far must not be overtaken by work on the new one
+    PDWT_HIP_TRY(hipStreamSynchronize(stream()));
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_user_set[dev] = use_it != 0;
+    g_user_streams[dev] = use_it ? (hipStream_t)user_stream : nullptr;
+    return PDWT_OK;
+}
 const char* pdwt_last_error_string(void) { return g_err; }
 
 void* pdwt_event_create(void)

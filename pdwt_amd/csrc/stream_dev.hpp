@@ -160,11 +160,6 @@ __device__ __forceinline__ void asm_drain1(V& a) { asm volatile("s_waitcnt vmcnt
 
 
 // ---- host helpers ----------------------------------------------------------------------------------
-static inline int env_int(const char* name, int dflt)
-{
-    const char* e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
-}
 static inline ChunkMap make_map(int gx, int nchunks, dim3* grid)
 {
     ChunkMap m;

@@ -267,13 +267,17 @@ __global__ __launch_bounds__(kUThreads) void k_circshift(const T* __restrict__ i
 
 #define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
 
-// per-device scratch for the reduction partials (+1 slot for the result)
+// per-device scratch for the reduction partials (+1 slot for the result).  One buffer per device shared by every
+// host thread: a reduction holds g_red_mu[dev] from its first launch until its result has been copied out, so two
+// threads reducing on one device cannot interleave their partials.
 static std::mutex g_mu;
+static std::mutex g_red_mu[64];
 static double* g_partials[64] = {};
-static double* partials()
+static double* partials(int* dev_out)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    *dev_out = dev;
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_partials[dev]) {
         if (hipMalloc(&g_partials[dev], (kMaxBlocks + 8) * sizeof(double)) != hipSuccess) g_partials[dev] = nullptr;
@@ -374,8 +378,9 @@ static int group_soft_thresh(T** c, T beta, pdwt_info w, int do_thresh_appcoeffs
 
 // sum over bands of |c| (mode 0) or c^2 (mode 1), in double.
 //   norm1   Wavelets::norm1, src/wt.cu:398-418: |c| over all bands including band 0
-//   norm2sq Wavelets::norm2sq, src/wt.cu:370-395: c^2 over all bands -- except that the reference's 1-D branch adds
-//           cublas_asum (sum |c|) of the detail bands (src/wt.cu:389, SURVEY B-4); reproduced when `ref_quirk_1d`.
+//   norm2sq Wavelets::norm2sq, src/wt.cu:370-395: c^2 over all bands.  The reference's 1-D branch adds cublas_asum
+//           (sum |c|) of the detail bands (src/wt.cu:389, SURVEY B-4): a bug, FIXED here (the squared l2 norm is
+//           returned); knob norm2sq_ref1d = 1 reproduces the reference value.
 template <typename T>
 static int band_sum_double(T** c, pdwt_info w, double* out, int squares, int ref_quirk_1d)
 {
@@ -387,11 +392,13 @@ static int band_sum_double(T** c, pdwt_info w, double* out, int squares, int ref
     tab.chunk0[0] = 0;
     bool vec = true;
     for (int k = 0; k < g.nbands; k++) {
-        const bool sq = squares && !(ref_quirk_1d && w.ndims == 1 && k > 0);
+        const bool sq = squares && !(ref_quirk_1d && knob(KN_NORM2SQ_REF1D) == 1 && w.ndims == 1 && k > 0);
         if (!table_push<T>(tab, c[k], (size_t)g.Nr[k] * g.Nc[k], sq ? T(1) : T(0), vec)) return PDWT_EINVAL;
     }
-    double* part = partials();
+    int dev = 0;
+    double* part = partials(&dev);
     if (!part) return PDWT_ENOMEM;
+    std::lock_guard<std::mutex> red_lock(g_red_mu[dev]);
     const unsigned int total = tab.chunk0[tab.nb];
     const int blocks = (int)(total < (unsigned)kMaxBlocks ? (total ? total : 1) : (unsigned)kMaxBlocks);
     {

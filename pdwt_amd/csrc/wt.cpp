@@ -10,6 +10,7 @@
 // Deliberate fixes ("F" items): per-instance filters (B-1); unknown wavelet
 // name or a clamp down to 0 levels is a creation error (B-2); return codes of the drivers are
 // checked and mapped onto W_FORWARD_ERROR / W_INVERSE_ERROR / W_THRESHOLD_ERROR (B-10).
+#include <limits.h>
 #include <string.h>
 #include <strings.h>
 
@@ -166,7 +167,7 @@ Wavelets::Wavelets(DTYPE* img, int Nr, int Nc, const char* wname_, int levels, i
     int rc;
     if (!img) rc = pdwt_memset(d_image, 0, nimg * sizeof(DTYPE));
     else if (memisonhost) rc = pdwt_memcpy_h2d(d_image, img, nimg * sizeof(DTYPE));
-    else rc = pdwt_memcpy_d2d(d_image, img, nimg * sizeof(DTYPE));
+    else rc = pdwt_memcpy_d2d_foreign(d_image, img, nimg * sizeof(DTYPE));
     if (rc != PDWT_OK) {
         report("Wavelets(): image upload", rc);
         state = W_CREATION_ERROR;
@@ -556,14 +557,14 @@ int Wavelets::get_image(DTYPE* res)
     if (!d_image || !res) return 0;
     const size_t n = (size_t)winfos.Nr * winfos.Nc;
     if (pdwt_memcpy_d2h(res, d_image, n * sizeof(DTYPE)) != PDWT_OK) return 0;
-    return (int)n;
+    return n > (size_t)INT_MAX ? INT_MAX : (int)n;  // element count as in the reference; saturates for >= 2^31 elements
 }
 
 void Wavelets::set_image(DTYPE* img, int mem_is_on_device)
 {
     if (!d_image || !img) return;
     const size_t nb = (size_t)winfos.Nr * winfos.Nc * sizeof(DTYPE);
-    int rc = mem_is_on_device ? pdwt_memcpy_d2d(d_image, img, nb) : pdwt_memcpy_h2d(d_image, img, nb);
+    int rc = mem_is_on_device ? pdwt_memcpy_d2d_foreign(d_image, img, nb) : pdwt_memcpy_h2d(d_image, img, nb);
     if (rc != PDWT_OK) report("Wavelets::set_image()", rc);
     if (state != W_CREATION_ERROR) state = W_INIT;
 }
@@ -583,7 +584,7 @@ void Wavelets::set_coeff(DTYPE* coeff, int num, int mem_is_on_device)
         return;
     }
     const size_t nb = (size_t)n * sizeof(DTYPE);
-    int rc = mem_is_on_device ? pdwt_memcpy_d2d(d_coeffs[num], coeff, nb) : pdwt_memcpy_h2d(d_coeffs[num], coeff, nb);
+    int rc = mem_is_on_device ? pdwt_memcpy_d2d_foreign(d_coeffs[num], coeff, nb) : pdwt_memcpy_h2d(d_coeffs[num], coeff, nb);
     if (rc != PDWT_OK) report("Wavelets::set_coeff()", rc);
 }
 
@@ -600,7 +601,7 @@ int Wavelets::get_coeff(DTYPE* coeff, int num)
         return 0;
     }
     if (pdwt_memcpy_d2h(coeff, d_coeffs[num], (size_t)n * sizeof(DTYPE)) != PDWT_OK) return 0;
-    return (int)n;
+    return n > (long long)INT_MAX ? INT_MAX : (int)n;  // saturates for >= 2^31 elements (SWT bands of huge images)
 }
 
 void Wavelets::print_informations()

@@ -35,6 +35,15 @@ class DeviceArray:
         return out
 
 
+def _sync_producer():
+    """A device buffer handed to the library was produced on SOME stream of the caller: wait for torch's current
+    stream (the usual producer; it need not be the NULL stream the C side waits for) before the pointer is used."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.current_stream().synchronize()
+
+
 def _device_source(img):
     """(pointer, shape, dtype) of an object that lives in device memory (torch tensor on the GPU or anything with
     ``__cuda_array_interface__``), else None."""
@@ -80,6 +89,7 @@ class Wavelets:
         self._L = N.host(self.dtype)
         self._ct = C.c_float if self.dtype == np.float32 else C.c_double
         if device_ptr is not None:
+            _sync_producer()
             src, on_host = C.c_void_p(int(device_ptr)), 0
         elif img is not None:
             src, on_host = img.ctypes.data_as(C.c_void_p), 1
@@ -221,7 +231,7 @@ class Wavelets:
     def get_image(self):
         out = np.empty(self.shape, dtype=self.dtype)
         n = self._L.pdwt_wavelets_get_image(self._h, out.ctypes.data_as(C.c_void_p))
-        if n != out.size:
+        if n != min(out.size, 2**31 - 1):  # the C++ method returns an int element count: saturated past 2^31 - 1
             raise RuntimeError("get_image failed")
         return out
 
@@ -243,6 +253,7 @@ class Wavelets:
             assert dev[2] == self.dtype and int(np.prod(dev[1])) == self.shape[0] * self.shape[1]
             img, mem_is_on_device = dev[0], 1
         if mem_is_on_device:
+            _sync_producer()
             self._L.pdwt_wavelets_set_image(self._h, C.c_void_p(int(img)), 1)
         else:
             a = np.ascontiguousarray(img, dtype=self.dtype)
@@ -253,7 +264,7 @@ class Wavelets:
         r, c = self.band_shape(num)
         out = np.empty((r, c), dtype=self.dtype)
         n = self._L.pdwt_wavelets_get_coeff(self._h, out.ctypes.data_as(C.c_void_p), int(num))
-        if n != out.size:
+        if n != min(out.size, 2**31 - 1):
             raise RuntimeError("get_coeff(%d) failed (state=%d)" % (num, self.state))
         return out
 
@@ -262,6 +273,7 @@ class Wavelets:
         dev = _device_source(arr)
         if dev is not None:
             assert dev[2] == self.dtype and int(np.prod(dev[1])) == r * c
+            _sync_producer()
             self._L.pdwt_wavelets_set_coeff(self._h, C.c_void_p(dev[0]), int(num), 1)
             return
         a = np.ascontiguousarray(arr, dtype=self.dtype)

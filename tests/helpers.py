@@ -35,6 +35,32 @@ def golden_bands(d):
     return [d["band%d" % i] for i in range(d["nbands"])]
 
 
+class knobs:
+    """with knobs(casc=0, casc_min=0): ...   -- set tuning knobs of libpdwt_hip.so (pdwt_debug_set), restore on exit."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+        self.old = {}
+
+    def __enter__(self):
+        import ctypes as C
+        import pdwt_amd
+        L = pdwt_amd.hip()
+        for k, v in self.kw.items():
+            cur = C.c_int()
+            assert L.pdwt_debug_get(k.encode(), C.byref(cur)) == 0, k
+            self.old[k] = cur.value
+            assert L.pdwt_debug_set(k.encode(), int(v)) == 0, k
+        return self
+
+    def __exit__(self, *exc):
+        import pdwt_amd
+        L = pdwt_amd.hip()
+        for k, v in self.old.items():
+            L.pdwt_debug_set(k.encode(), v)
+        return False
+
+
 KIND = {"dwt2": dict(do_swt=0, ndim=2), "dwt1": dict(do_swt=0, ndim=1), "swt2": dict(do_swt=1, ndim=2), "swt1": dict(do_swt=1, ndim=1)}
 
 GOLDEN_CASES = [
