@@ -37,8 +37,9 @@ struct CascGeom {
 };
 
 struct CascMap {
-    int cpx;     // chunk rows per XCD (all 8 XCDs get the same number)
-    int strips;  // strips (= waves) per chunk row
+    int cpx;     // W == 1: chunk rows per XCD (all 8 XCDs get the same number); W > 1: workgroups per XCD
+    int strips;  // strips per chunk row
+    int gy;      // W > 1: workgroup-chunk rows (gy * strips workgroups in all)
 };
 struct CascBands {
     float *H1, *V1, *D1, *A2, *H2, *V2, *D2;
@@ -56,35 +57,81 @@ constexpr int casc_fwd_after(int p)
     return n;
 }
 
+// LDS hand-off area of a W-wave workgroup: one region per CONSUMER wave k in [0, W-1), written by wave k+1:
+//   (HLEN-2) ring rows of 64 lanes x 16 B  (level-1 row-pass results of the producer's first HLEN-2 input rows)
+//   (HLEN-2) ring2 rows of 64 lanes x 8 B  (level-2 row-pass results of the producer's first HLEN-2 A1 rows)
+template <int HLEN>
+constexpr int casc_fwd_region_bytes() { return (HLEN - 2) * 64 * (16 + 8); }
+
 // NV = row registers = input rows (KiB) in flight per wave = prefetch distance (HLEN/2, HLEN or 2*HLEN)
-template <int HLEN, int NV>
-__global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in, CascBands b, int Nr, int Nc, int VL,
-                                                     float* __restrict__ trash, CascMap cm, TapsLH f)
+// W  = waves of a workgroup stacked vertically in ONE strip (1 = independent waves, four strips per workgroup).
+//
+// Chunk-local numbering (all W): local input row 0 = global 4*j0 - 3C for a wave whose level-2 rows are [j0, j0+rows2);
+// A1 row n <-> local input rows 2n .. 2n+HLEN-1; level-2 row jl <-> A1 rows 2jl .. 2jl+HLEN-1.  A wave OWNS (stores) the
+// level-1 rows n in [0, NA), NA = 2*rows2 -- global row 2*j0 + n - C -- and the level-2 rows jl in [0, rows2).  Its last
+// HLEN/2-1 own A1 rows need HLEN-2 input rows beyond its 2*NA first-hand ones, its last HLEN/2-1 level-2 rows need HLEN-2
+// A1 rows beyond NA: exactly the rows the wave BELOW starts with.
+//   W == 1 (and the last wave of a workgroup): recompute -- load the 3(HLEN-2) extra input rows, run NA1 = NA+HLEN-2 A1 rows.
+//   W  > 1: the wave below has those row-pass results in its rings anyway (its ring warm-up).  It drops them in LDS during
+//           its first super-body; one s_barrier later every wave can pick up its bottom halo at the END of its chunk: no
+//           extra loads, no recomputation, and the waves of a workgroup are balanced by giving the last one fewer rows.
+template <int HLEN, int NV, int W>
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const float* __restrict__ in, CascBands b, int Nr, int Nc, int VL,
+                                                                       float* __restrict__ trash, CascMap cm, TapsLH f)
 {
     using G = CascGeom<HLEN>;
     constexpr int C = G::C, NB1 = G::NB1, NB2 = G::NB2, NBT = G::NBT, WIN1 = G::WIN1, WIN2 = G::WIN2;
-    // wave -> (chunk row, strip): XCD x (= blockIdx % 8, private L2) owns the contiguous band of chunk rows
-    // [x*cpx, (x+1)*cpx) and its waves walk that band strip by strip, so neighbours in space are neighbours in time
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
-    const int xcd = blockIdx.x & 7;
+    const int Nc2 = Nc >> 1, Nr2 = Nr >> 1, Nr4 = Nr >> 2, Nc4 = Nc >> 2;
     // the wave index is uniform, but only readfirstlane tells the compiler: everything derived from it (rows, row
     // bases, trip counts, predicates) then lives on the scalar unit
-    const int wi = (blockIdx.x >> 3) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wi >= cm.cpx * cm.strips) return;
-    const int cy = xcd * cm.cpx + wi / cm.strips;
-    const int strip = wi % cm.strips;
+    const int kw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int j0, rows2, strip;
+    bool last;  // this wave recomputes its bottom halo (nobody hands it over)
+    if constexpr (W == 1) {
+        // wave -> (chunk row, strip): XCD x (= blockIdx % 8, private L2) owns the contiguous band of chunk rows
+        // [x*cpx, (x+1)*cpx) and its waves walk that band strip by strip, so neighbours in space are neighbours in time
+        const int xcd = blockIdx.x & 7;
+        const int wi = (blockIdx.x >> 3) * 4 + kw;
+        if (wi >= cm.cpx * cm.strips) return;
+        const int cy = xcd * cm.cpx + wi / cm.strips;
+        strip = wi % cm.strips;
+        const int nchunks = 8 * cm.cpx;
+        j0 = (int)(((long long)cy * Nr4) / nchunks);  // level-2 rows [j0, j1) of the chunk
+        rows2 = (int)(((long long)(cy + 1) * Nr4) / nchunks) - j0;
+        if (rows2 <= 0) return;
+        last = true;
+    } else {
+        // workgroup -> (workgroup-chunk row, strip); XCD x owns the logical workgroups [x*cpx, (x+1)*cpx)
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int wg = xcd * cm.cpx + slot;
+        if (slot >= cm.cpx || wg >= cm.gy * cm.strips) return;  // (uniform over the workgroup: nobody is left at the barrier)
+        const int gy = wg / cm.strips;
+        strip = wg % cm.strips;
+        const int J0 = (int)(((long long)gy * Nr4) / cm.gy);
+        const int R = (int)(((long long)(gy + 1) * Nr4) / cm.gy) - J0;
+        // split of the R level-2 rows: the last wave also streams the 3(HLEN-2) halo input rows below the workgroup's
+        // chunk (worth E level-2 rows of work), so it gets E rows fewer (at least one is left); the host guarantees
+        // R / W >= HLEN / 2 (two barriers in the first super-body order the hand-off, see the loop)
+        const int E = min((3 * (HLEN - 2) + 3) / 4, R / W - 1);
+        const int base = (R + E) / W, rem = (R + E) % W;
+        const int start = kw * base + min(kw, rem);
+        rows2 = (kw < W - 1) ? base + (kw < rem ? 1 : 0) : R - start;
+        j0 = J0 + start;
+        last = (kw == W - 1);
+    }
     const int xs = strip * VL * 4;  // first input column this strip produces outputs for
-    const int Nc2 = Nc >> 1, Nr4 = Nr >> 2, Nc4 = Nc >> 2;
-    const int nchunks = 8 * cm.cpx;
-    const int j0 = (int)(((long long)cy * Nr4) / nchunks);  // level-2 rows [j0, j1) of the chunk
-    const int rows2 = (int)(((long long)(cy + 1) * Nr4) / nchunks) - j0;
-    if (rows2 <= 0) return;
     const int x = xs + 4 * (lane - NBT);
     const bool valid = (lane >= NBT) && (lane < NBT + VL) && (x < Nc);
     const int xo = wrapi(x, Nc);
-    const int yb = 4 * j0 - 3 * C;           // input row of chunk-local row 0 (A1 row n <-> input rows 2n .. 2n+HLEN-1)
-    const int NA1 = 2 * rows2 + HLEN - 2;    // A1 rows the chunk computes; n in [C, C+2*rows2) are its own
-    const int rlast = 2 * NA1 + HLEN - 3;    // last input row the chunk needs
+    const int yb = 4 * j0 - 3 * C;           // global input row of chunk-local row 0
+    const int NA = 2 * rows2;                // A1 rows the wave owns
+    const int NA1 = NA + HLEN - 2;           // A1 rows it runs through (the last HLEN-2 only feed level 2)
+    // W > 1, not the last wave: A1 rows >= NL1 take their two new input rows from the hand-off area, A1 rows >= NA are not
+    // computed at all (their level-2 row-pass results come from the hand-off area)
+    const int NL1 = NA - HLEN / 2 + 1;
+    const int rlast = last ? 2 * NA1 + HLEN - 3 : 2 * NA - 1;  // last input row the wave loads
 
     v2f ring[HLEN][2];  // level 1: (lo,hi) row-pass results of the last HLEN input rows, 2 columns
     v2f ring2[HLEN];    // level 2: (lo,hi) row-pass results of the last HLEN A1 rows, 1 column
@@ -96,6 +143,13 @@ __global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in
     // steady state: uniform row base on the scalar unit + loop-invariant per-lane byte offset (stream_dev.hpp)
     auto rowbase = [&](int r) { return in + (size_t)wrap1(yb + r, Nr) * Nc; };
     const unsigned xoff = (unsigned)xo * 4u;
+
+    // hand-off area: region kw is READ by this wave (written by wave kw+1), region kw-1 is WRITTEN by it
+    constexpr int REG = casc_fwd_region_bytes<HLEN>();
+    unsigned char* const lds_rd = lds_raw + (size_t)(W > 1 ? kw : 0) * REG;
+    unsigned char* const lds_wr = lds_raw + (size_t)(W > 1 && kw > 0 ? kw - 1 : 0) * REG;
+    auto lds_ring = [&](unsigned char* reg, int r) { return reinterpret_cast<v4f*>(reg + ((size_t)r * 64 + lane) * 16); };
+    auto lds_ring2 = [&](unsigned char* reg, int r) { return reinterpret_cast<v2f*>(reg + (size_t)(HLEN - 2) * 64 * 16 + ((size_t)r * 64 + lane) * 8); };
 
     auto row_pass1 = [&](const v4f& v, v2f (&lh)[2]) {
         float w[WIN1];
@@ -146,11 +200,18 @@ __global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in
 #pragma unroll
         for (int r = 0; r < HLEN - 2; r++) pv[r] = *reinterpret_cast<const v4f*>(rowptr(r));
 #pragma unroll
-        for (int u = 0; u < NV; u++) v[u] = *reinterpret_cast<const v4f*>(rowptr(HLEN - 2 + u));
+        for (int u = 0; u < NV; u++) v[u] = *reinterpret_cast<const v4f*>(rowptr(min(HLEN - 2 + u, rlast)));
         static_for<HLEN - 2>([&](auto Rr) {
             constexpr int r = decltype(Rr)::value;
             row_pass1(pv[r], ring[r]);
         });
+    }
+    if constexpr (W > 1) {
+        // hand over the ring warm-up rows: the wave above needs exactly these at the end of its chunk
+        if (kw > 0) {
+#pragma unroll
+            for (int r = 0; r < HLEN - 2; r++) *lds_ring(lds_wr, r) = v4f{ring[r][0].x, ring[r][0].y, ring[r][1].x, ring[r][1].y};
+        }
     }
 
     float* const tr = trash + (size_t)(blockIdx.x & 15) * Nc2;  // a trash ROW (the dispatcher checks the area holds 16 of them)
@@ -163,38 +224,59 @@ __global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in
             constexpr int s0 = (2 * u + HLEN - 2) % HLEN, s1 = (2 * u + HLEN - 1) % HLEN;
             const int n = sb * HLEN + a;  // chunk-local A1 row
             constexpr int r0 = (2 * a) % NV, r1 = r0 + 1;
-            // v[r0], v[r1] were loaded DIST A1 rows ago, at position (a - DIST) mod HLEN
-            asm_wait2<casc_fwd_after<DIST>((a + HLEN - DIST) % HLEN)>(v[r0], v[r1]);
-            row_pass1(v[r0], ring[s0]);
-            row_pass1(v[r1], ring[s1]);
-            const int rn = 2 * n + HLEN - 2 + NV;  // the rows these registers hold DIST A1 rows ahead
-            // (clamped to the chunk's last row: the prefetch past the end re-reads a cached line instead of fetching new ones)
-            asm_load_s(v[r0], rowbase(min(rn, rlast)), xoff);
-            asm_load_s(v[r1], rowbase(min(rn + 1, rlast)), xoff);
-            // level-1 column pass
-            v2f ah[2], vd[2];
-#pragma unroll
-            for (int p = 0; p < 2; p++) ah[p] = vd[p] = v2f{0.f, 0.f};
-            static_for<HLEN>([&](auto J) {
-                constexpr int j = decltype(J)::value;
-                constexpr int s = (2 * u + j) % HLEN;
-                const v2f t = f.t[HLEN - 1 - j];
-#pragma unroll
-                for (int p = 0; p < 2; p++) {
-                    ah[p] = pk_fma(splat(ring[s][p].x), t, ah[p]);
-                    vd[p] = pk_fma(splat(ring[s][p].y), t, vd[p]);
+            const bool mem1 = (W == 1) || last || (n < NL1);   // the two new input rows come from memory
+            const bool comp = (W == 1) || last || (n < NA);    // the A1 row is computed here
+            if (mem1) {
+                // v[r0], v[r1] were loaded DIST A1 rows ago, at position (a - DIST) mod HLEN
+                asm_wait2<casc_fwd_after<DIST>((a + HLEN - DIST) % HLEN)>(v[r0], v[r1]);
+                row_pass1(v[r0], ring[s0]);
+                row_pass1(v[r1], ring[s1]);
+            } else if (comp) {
+                if constexpr (W > 1) {  // ... or from the wave below (its ring warm-up rows)
+                    const int i0 = 2 * (n - NL1);
+                    const v4f q0 = *lds_ring(lds_rd, i0), q1 = *lds_ring(lds_rd, i0 + 1);
+                    ring[s0][0] = v2f{q0.x, q0.y};
+                    ring[s0][1] = v2f{q0.z, q0.w};
+                    ring[s1][0] = v2f{q1.x, q1.y};
+                    ring[s1][1] = v2f{q1.z, q1.w};
                 }
-            });
-            {
-                // rows outside the chunk's own range go to the trash rows (uniform select on the scalar unit)
-                const bool own = (n >= C) && (n < C + 2 * rows2);
-                const size_t o = (size_t)(2 * j0 + n - C) * Nc2;
-                asm_store_sm(own ? b.H1 + o : tr, off1, v2f{ah[0].y, ah[1].y}, vmask);
-                asm_store_sm(own ? b.V1 + o : tr, off1, v2f{vd[0].x, vd[1].x}, vmask);
-                asm_store_sm(own ? b.D1 + o : tr, off1, v2f{vd[0].y, vd[1].y}, vmask);
             }
-            // level-2 row pass on the A1 pair; ring2 slot = n % HLEN = a
-            row_pass2(ah[0].x, ah[1].x, ring2[a]);
+            if (comp) {
+                const int rn = 2 * n + HLEN - 2 + NV;  // the rows these registers hold DIST A1 rows ahead
+                // (clamped to the wave's last row: the prefetch past the end re-reads a cached line instead of fetching new ones)
+                asm_load_s(v[r0], rowbase(min(rn, rlast)), xoff);
+                asm_load_s(v[r1], rowbase(min(rn + 1, rlast)), xoff);
+                // level-1 column pass
+                v2f ah[2], vd[2];
+#pragma unroll
+                for (int p = 0; p < 2; p++) ah[p] = vd[p] = v2f{0.f, 0.f};
+                static_for<HLEN>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    constexpr int s = (2 * u + j) % HLEN;
+                    const v2f t = f.t[HLEN - 1 - j];
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        ah[p] = pk_fma(splat(ring[s][p].x), t, ah[p]);
+                        vd[p] = pk_fma(splat(ring[s][p].y), t, vd[p]);
+                    }
+                });
+                {
+                    // rows the wave does not own (the recomputed halo) go to the trash rows (uniform select on the scalar unit)
+                    const bool own = n < NA;
+                    const size_t o = (size_t)wrap1(2 * j0 + n - C, Nr2) * Nc2;
+                    asm_store_sm(own ? b.H1 + o : tr, off1, v2f{ah[0].y, ah[1].y}, vmask);
+                    asm_store_sm(own ? b.V1 + o : tr, off1, v2f{vd[0].x, vd[1].x}, vmask);
+                    asm_store_sm(own ? b.D1 + o : tr, off1, v2f{vd[0].y, vd[1].y}, vmask);
+                }
+                // level-2 row pass on the A1 pair; ring2 slot = n % HLEN = a
+                row_pass2(ah[0].x, ah[1].x, ring2[a]);
+                if constexpr (W > 1 && a < HLEN - 2) {
+                    // first super-body: the wave above needs the row-pass results of this wave's first HLEN-2 A1 rows
+                    if (sb == 0 && kw > 0) *lds_ring2(lds_wr, a) = ring2[a];
+                }
+            } else {
+                if constexpr (W > 1) ring2[a] = *lds_ring2(lds_rd, min(n - NA, HLEN - 3));
+            }
             if constexpr (a & 1) {
                 // A1 rows n-HLEN+1 .. n complete the window of level-2 row (n-(HLEN-1))/2
                 v2f ah2 = {0.f, 0.f}, vd2 = {0.f, 0.f};
@@ -216,8 +298,17 @@ __global__ __launch_bounds__(256) void k_fwd2d_casc(const float* __restrict__ in
     };
     for (int sb = 0;; sb++) {
         static_for<HLEN / 2>([&](auto U) { a1_row(std::integral_constant<int, decltype(U)::value>{}, sb); });
+        // Hand-off order (W > 1): the ring rows are written in the prologue and first read at A1 row NL1 >= HLEN/2, the ring2 rows
+        // are written at A1 rows 0..HLEN-3 and first read at A1 row NA >= HLEN -- one barrier after each half of the FIRST
+        // super-body (every wave runs both halves: NA1 >= HLEN for rows2 >= 1).  LDS only: the global loads in flight are not drained.
+        if constexpr (W > 1) {
+            if (sb == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         if (sb * HLEN + HLEN / 2 >= NA1) break;
         static_for<HLEN / 2>([&](auto U) { a1_row(std::integral_constant<int, decltype(U)::value + HLEN / 2>{}, sb); });
+        if constexpr (W > 1) {
+            if (sb == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         if (sb * HLEN + HLEN >= NA1) break;
     }
     static_for<NV>([&](auto K) { asm_drain1(v[decltype(K)::value]); });
@@ -546,24 +637,56 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
     constexpr int MAXVL = CascGeom<HLEN>::MAXVL;
     const int strips = idiv_up(nc, MAXVL * 4);
     const int VL = idiv_up(nc / 4, strips);
-    // chunk rows: a multiple of 8 (one band per XCD), ~PDWT_CASC_WAVES waves in total, at least 4 level-2 rows each.
-    // One wave per SIMD (1024) is the optimum: every extra chunk row recomputes 3(hlen-2) input rows of halo
+    constexpr int NVD = (HLEN % 4 == 0 ? HLEN / 2 : HLEN);  // default prefetch distance
+    KTimer kt(K_FWD2D_CASC, true);
+    // ---- workgroup form: W waves stacked in one strip hand their ring warm-up rows to the wave above through LDS, so only the
+    // LAST wave of a workgroup re-reads and recomputes the 3(hlen-2) halo input rows (C2: 14 x 18 workgroups of 4 waves
+    // stream 4096 + 14*18 rows per strip instead of 4096 + 56*18)
+    int W = knob(KN_CASC_WG);
+    if (W == 0) W = 16;  // C2 forward: 25.1 us independent waves, 24.6 W=8, 23.2 W=16 (252 workgroups each)
+    if (W != 1 && W != 4 && W != 8 && W != 16) W = 16;
+    constexpr size_t REG = casc_fwd_region_bytes<HLEN>();
+    while (W > 1 && (size_t)(W - 1) * REG > 150 * 1024) W /= 2;  // the hand-off area must fit the 160 KiB of LDS
+    if (W == 2) W = 1;
+    if (W > 1) {
+        const int wgs = knob(KN_CASC_WAVES) > 0 ? idiv_up(knob(KN_CASC_WAVES), W) : 256;  // default: one workgroup per CU
+        int gy = wgs / strips;
+        const int nr4 = nr / 4;
+        while (gy > 1 && (nr4 / gy) / W < HLEN / 2) gy--;  // every wave needs >= HLEN/2 level-2 rows (see the kernel)
+        if (gy >= 1 && (nr4 / gy) / W >= HLEN / 2) {
+            const int nwg = gy * strips;
+            const CascMap cm = {idiv_up(nwg, 8), strips, gy};
+            const dim3 grid((unsigned)(8 * cm.cpx));
+            const size_t lds = (size_t)(W - 1) * REG;
+            const int nv = knob(KN_CASC_NV) > 0 ? knob(KN_CASC_NV) : NVD;
+            void (*k)(const float*, CascBands, int, int, int, float*, CascMap, TapsLH);
+            const bool deep = (nv >= HLEN) && (HLEN % 4 == 0) && (2 * HLEN <= 16);  // HLEN row registers in flight instead of HLEN/2
+            if (W == 4) k = deep ? k_fwd2d_casc<HLEN, HLEN, 4> : k_fwd2d_casc<HLEN, NVD, 4>;
+            else if (W == 8) k = deep ? k_fwd2d_casc<HLEN, HLEN, 8> : k_fwd2d_casc<HLEN, NVD, 8>;
+            else k = deep ? k_fwd2d_casc<HLEN, HLEN, 16> : k_fwd2d_casc<HLEN, NVD, 16>;
+            if (lds > 64 * 1024) PDWT_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PDWT_LAUNCH_KT(kt, k, grid, dim3(64 * W), lds, in, b, nr, nc, VL, trash, cm, f);
+            PDWT_CHECK_LAUNCH();
+            return PDWT_OK;
+        }
+    }
+    // ---- independent waves.  chunk rows: a multiple of 8 (one band per XCD), ~PDWT_CASC_WAVES waves in total, at least 4
+    // level-2 rows each.  One wave per SIMD (1024) is the optimum: every extra chunk row recomputes 3(hlen-2) input rows of halo
     // (measured 27.2 us @1024, 30.9 @2048, 35 @4096 for 4096^2 db4).
     int cpx = (knob(KN_CASC_WAVES) > 0 ? knob(KN_CASC_WAVES) : 1024) / (8 * strips);
     if (cpx > nr / 4 / 4 / 8) cpx = nr / 4 / 4 / 8;
     if (cpx < 1) cpx = 1;
-    const CascMap cm = {cpx, strips};
+    const CascMap cm = {cpx, strips, 0};
     const dim3 grid((unsigned)(8 * idiv_up(cpx * strips, 4)));
-    KTimer kt(K_FWD2D_CASC, true);
     // row registers in flight (= prefetch distance): HLEN/2 measured best (26.2 us vs 26.8 @HLEN, 28.5 @2*HLEN for 4096^2 db4);
     // a shorter pipeline fills and drains faster, and every wave fills and drains at the same time
-    const int nv = knob(KN_CASC_NV) > 0 ? knob(KN_CASC_NV) : (HLEN % 4 == 0 ? HLEN / 2 : HLEN);
+    const int nv = knob(KN_CASC_NV) > 0 ? knob(KN_CASC_NV) : NVD;
     if (nv == 2)
-        PDWT_LAUNCH_KT(kt, (k_fwd2d_casc<HLEN, 2>), grid, dim3(256), 0, in, b, nr, nc, VL, trash, cm, f);
+        PDWT_LAUNCH_KT(kt, (k_fwd2d_casc<HLEN, 2, 1>), grid, dim3(256), 0, in, b, nr, nc, VL, trash, cm, f);
     else if (nv < HLEN && HLEN % 4 == 0)
-        PDWT_LAUNCH_KT(kt, (k_fwd2d_casc<HLEN, (HLEN % 4 == 0 ? HLEN / 2 : HLEN)>), grid, dim3(256), 0, in, b, nr, nc, VL, trash, cm, f);
+        PDWT_LAUNCH_KT(kt, (k_fwd2d_casc<HLEN, NVD, 1>), grid, dim3(256), 0, in, b, nr, nc, VL, trash, cm, f);
     else
-        PDWT_LAUNCH_KT(kt, (k_fwd2d_casc<HLEN, HLEN>), grid, dim3(256), 0, in, b, nr, nc, VL, trash, cm, f);
+        PDWT_LAUNCH_KT(kt, (k_fwd2d_casc<HLEN, HLEN, 1>), grid, dim3(256), 0, in, b, nr, nc, VL, trash, cm, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -597,7 +720,7 @@ static int launch_inv_casc(const CascInvBands& b, float* out, float* trash, int 
     int cpx = (knob(KN_CASC_IWAVES) > 0 ? knob(KN_CASC_IWAVES) : 2048) / (8 * strips);
     if (cpx > nr / 2 / 8 / 8) cpx = nr / 2 / 8 / 8;  // at least 8 level-l coefficient rows per chunk
     if (cpx < 1) cpx = 1;
-    const CascMap cm = {cpx, strips};
+    const CascMap cm = {cpx, strips, 0};
     const dim3 grid((unsigned)(8 * idiv_up(cpx * strips, 4)));
     KTimer kt(K_INV2D_CASC, true);
     constexpr int H2 = HLEN / 2;
