@@ -1,0 +1,53 @@
+// casc_dev.hpp -- geometry and argument structs shared by the multi-level-per-launch kernels
+// (dwt_casc.hip: forward + independent-wave inverse; dwt_casc_invw.hip: workgroup-form inverse, two or three levels).
+#pragma once
+#include "common.hpp"
+
+namespace pdwt {
+
+template <int HLEN>
+struct CascGeom {
+    static constexpr int C = HLEN / 2 - 1;                      // halo samples per side, both levels
+    static constexpr int NB1 = C > 0 ? (C + 3) / 4 : 0;         // halo lanes for the input window (4 columns per lane)
+    static constexpr int NB2 = C > 0 ? (C + 1) / 2 : 0;         // halo lanes for the A1 window (2 columns per lane)
+    static constexpr int NBT = NB1 + NB2;                       // lanes per side that produce no output
+    static constexpr int WIN1 = 4 * (2 * NB1 + 1);
+    static constexpr int WIN2 = 2 * (2 * NB2 + 1);
+    static constexpr int MAXVL = 64 - 2 * NBT;
+};
+
+struct CascMap {
+    int cpx;     // W == 1: chunk rows per XCD (all 8 XCDs get the same number); W > 1: workgroups per XCD
+    int strips;  // strips per chunk row
+    int gy;      // W > 1: workgroup-chunk rows (gy * strips workgroups in all)
+};
+struct CascBands {
+    float *H1, *V1, *D1, *A2, *H2, *V2, *D2;
+};
+
+template <int HLEN>
+struct CascInvGeom {
+    static constexpr int H2 = HLEN / 2;
+    static constexpr int C = H2 / 2;
+    static constexpr int SHIFT = (H2 & 1) ? 0 : 1;
+    static constexpr int NB1 = C > 0 ? (C + 1) / 2 : 0;  // halo lanes, level l (2 coefficient columns per lane)
+    static constexpr int NB2 = C;                         // halo lanes, level l+1 (1 column per lane)
+    static constexpr int NBT = NB1 + NB2;
+    static constexpr int WIN1 = 2 * (2 * NB1 + 1);
+    static constexpr int WIN2 = 2 * NB2 + 1;
+    static constexpr int MAXVL = 64 - 2 * NBT;
+    // chunks start at level-l coefficient rows of this parity so that the first A_l row a chunk needs
+    // (ya - C) is the first of the pair a level-(l+1) step produces (rows 2P-SHIFT, 2P+1-SHIFT)
+    static constexpr int BASE = (C - SHIFT) & 1;
+    static constexpr int VM_SB = H2 * (4 + 2 * (3 + 2));  // VMEM instructions per super-body
+};
+struct CascInvBands {
+    const float *A2, *H2, *V2, *D2, *H1, *V1, *D1;
+};
+
+
+int inv2d_cascw_f32(const float* A2, const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1,
+                    const float* A3, const float* H3, const float* V3, const float* D3, float* out, float* trash, int nr, int nc, int hlen,
+                    const Taps2<float>& f);
+
+}  // namespace pdwt

@@ -84,7 +84,9 @@ enum KnobId {
     KN_CASC_MIN,           // smallest input (pixels) the cascade kernels take
     KN_CASC_IWAVES,        // inverse cascade: waves per launch (0 = auto)
     KN_CASC_IPFD,          // inverse cascade: prefetch distance in steps
-    KN_CASC_WG,            // cascade kernels: waves stacked per workgroup with LDS ring hand-off (0 = auto, 1 = independent waves)
+    KN_CASC_WG,            // forward cascade: waves stacked per workgroup with LDS ring hand-off (0 = auto, 1 = independent waves)
+    KN_CASC_IWG,           // inverse cascade: the same (0 = auto, 1 = independent waves)
+    KN_CASC_L3,            // 0: never fold a third level into the inverse cascade launch
     KN_STREAM,             // 0: LDS-tiled fused level kernels instead of the streaming ones
     KN_STREAM_R,           // streaming level kernels: rows per wave (0 = auto)
     KN_STREAM_WAVES,       // streaming level kernels: target waves per launch

@@ -28,6 +28,7 @@
 #include "dwt1d_fused.hpp"
 #include "dwt_stream.hpp"
 #include "dwt_casc.hpp"
+#include "casc_dev.hpp"
 
 namespace pdwt {
 
@@ -722,9 +723,33 @@ static int inverse_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typ
         if constexpr (sizeof(T) == 4) {
             // levels i and i-1 in one launch, the approximation between them stays in registers (dwt_casc.hip);
             // pairs are (1,0), (3,2), ... so that the finest -- most expensive -- level is always in a pair
+            float* trash = s.t1_is_trash ? (float*)s.t1 : nullptr;
+            // levels i, i-1 and i-2 in one launch (dwt_casc_invw.hip): the approximation of level i-1 is synthesised from the
+            // level-i bands by the waves that need it and never goes to memory
+            if (i >= 2 && !(i & 1) && !force_twopass()) {
+                T* out = (i == 2) ? d_image : s.ping[pp];
+                rc = inv2d_cascw_f32(nullptr, c[3 * i - 2], c[3 * i - 1], c[3 * i], c[3 * i - 5], c[3 * i - 4], c[3 * i - 3], a, c[3 * i + 1],
+                                     c[3 * i + 2], c[3 * i + 3], out, trash, tNr[i - 2], tNc[i - 2], w.hlen, f);
+                if (rc < 0) return rc;
+                if (rc == PDWT_OK) {
+                    a = out;
+                    pp ^= 1;
+                    i -= 2;
+                    continue;
+                }
+            }
             if ((i & 1) && !force_twopass()) {
                 T* out = (i == 1) ? d_image : s.ping[pp];
-                float* trash = s.t1_is_trash ? (float*)s.t1 : nullptr;
+                // workgroup form first (ring hand-off through LDS instead of a recomputed halo per wave)
+                rc = inv2d_cascw_f32(a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], c[3 * i - 2], c[3 * i - 1], c[3 * i], nullptr, nullptr, nullptr,
+                                     nullptr, out, trash, tNr[i - 1], tNc[i - 1], w.hlen, f);
+                if (rc < 0) return rc;
+                if (rc == PDWT_OK) {
+                    a = out;
+                    pp ^= 1;
+                    i--;
+                    continue;
+                }
                 rc = inv2d_casc_f32(a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], c[3 * i - 2], c[3 * i - 1], c[3 * i], out, trash, tNr[i - 1],
                                     tNc[i - 1], w.hlen, f);
                 if (rc < 0) return rc;

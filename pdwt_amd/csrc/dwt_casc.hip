@@ -20,30 +20,13 @@
 // (src/separable.cu:179-209, 332-364) with their four kernels each.
 #include "dwt_casc.hpp"
 
+#include <algorithm>
+
 #include "dwt_stream.hpp"
 #include "stream_dev.hpp"
+#include "casc_dev.hpp"
 
 namespace pdwt {
-
-template <int HLEN>
-struct CascGeom {
-    static constexpr int C = HLEN / 2 - 1;                      // halo samples per side, both levels
-    static constexpr int NB1 = C > 0 ? (C + 3) / 4 : 0;         // halo lanes for the input window (4 columns per lane)
-    static constexpr int NB2 = C > 0 ? (C + 1) / 2 : 0;         // halo lanes for the A1 window (2 columns per lane)
-    static constexpr int NBT = NB1 + NB2;                       // lanes per side that produce no output
-    static constexpr int WIN1 = 4 * (2 * NB1 + 1);
-    static constexpr int WIN2 = 2 * (2 * NB2 + 1);
-    static constexpr int MAXVL = 64 - 2 * NBT;
-};
-
-struct CascMap {
-    int cpx;     // W == 1: chunk rows per XCD (all 8 XCDs get the same number); W > 1: workgroups per XCD
-    int strips;  // strips per chunk row
-    int gy;      // W > 1: workgroup-chunk rows (gy * strips workgroups in all)
-};
-struct CascBands {
-    float *H1, *V1, *D1, *A2, *H2, *V2, *D2;
-};
 
 // forward: VMEM instructions a wave issues per A1 row `p` of a super-body after that row's two loads
 constexpr int casc_fwd_stores(int p) { return 3 + 4 * (p & 1); }
@@ -327,26 +310,6 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
 // row registers of a step are re-issued for the same step ONE SUPER-BODY AHEAD; all loads/stores are inline
 // asm with exact s_waitcnt counts (14 VMEM per step: 4 loads, then per A_l row 3 loads + 2 stores).
 // The recomputed halo lands on the coarse level (4x less data), so it is cheap in this direction.
-template <int HLEN>
-struct CascInvGeom {
-    static constexpr int H2 = HLEN / 2;
-    static constexpr int C = H2 / 2;
-    static constexpr int SHIFT = (H2 & 1) ? 0 : 1;
-    static constexpr int NB1 = C > 0 ? (C + 1) / 2 : 0;  // halo lanes, level l (2 coefficient columns per lane)
-    static constexpr int NB2 = C;                         // halo lanes, level l+1 (1 column per lane)
-    static constexpr int NBT = NB1 + NB2;
-    static constexpr int WIN1 = 2 * (2 * NB1 + 1);
-    static constexpr int WIN2 = 2 * NB2 + 1;
-    static constexpr int MAXVL = 64 - 2 * NBT;
-    // chunks start at level-l coefficient rows of this parity so that the first A_l row a chunk needs
-    // (ya - C) is the first of the pair a level-(l+1) step produces (rows 2P-SHIFT, 2P+1-SHIFT)
-    static constexpr int BASE = (C - SHIFT) & 1;
-    static constexpr int VM_SB = H2 * (4 + 2 * (3 + 2));  // VMEM instructions per super-body
-};
-struct CascInvBands {
-    const float *A2, *H2, *V2, *D2, *H1, *V1, *D1;
-};
-
 // PFD = prefetch distance in steps (row registers are re-issued for the step PFD steps ahead; H2 % PFD == 0)
 template <int HLEN, int PFD>
 __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __restrict__ out, int Nr, int Nc, int VL,
@@ -649,21 +612,21 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
     while (W > 1 && (size_t)(W - 1) * REG > 150 * 1024) W /= 2;  // the hand-off area must fit the 160 KiB of LDS
     if (W == 2) W = 1;
     if (W > 1) {
-        const int wgs = knob(KN_CASC_WAVES) > 0 ? idiv_up(knob(KN_CASC_WAVES), W) : 256;  // default: one workgroup per CU
-        int gy = wgs / strips;
         const int nr4 = nr / 4;
+        // one workgroup per CU; if the image is too short for W waves of >= HLEN/2 level-2 rows each at that count, fewer waves
+        // per workgroup rather than fewer workgroups (2048^2 db4: 20.8 us with 72 workgroups of 16, 15.9 with 252 of 4)
+        const int wgs = knob(KN_CASC_WAVES) > 0 ? idiv_up(knob(KN_CASC_WAVES), W) : 256;
+        int gy = std::max(1, wgs / strips);
+        while (W > 4 && (nr4 / gy) / W < HLEN / 2) W /= 2;
         while (gy > 1 && (nr4 / gy) / W < HLEN / 2) gy--;  // every wave needs >= HLEN/2 level-2 rows (see the kernel)
         if (gy >= 1 && (nr4 / gy) / W >= HLEN / 2) {
             const int nwg = gy * strips;
             const CascMap cm = {idiv_up(nwg, 8), strips, gy};
             const dim3 grid((unsigned)(8 * cm.cpx));
             const size_t lds = (size_t)(W - 1) * REG;
-            const int nv = knob(KN_CASC_NV) > 0 ? knob(KN_CASC_NV) : NVD;
+            // (HLEN row registers in flight instead of HLEN/2 measured slower in this form too: 24.8 vs 24.6 us at W = 8)
             void (*k)(const float*, CascBands, int, int, int, float*, CascMap, TapsLH);
-            const bool deep = (nv >= HLEN) && (HLEN % 4 == 0) && (2 * HLEN <= 16);  // HLEN row registers in flight instead of HLEN/2
-            if (W == 4) k = deep ? k_fwd2d_casc<HLEN, HLEN, 4> : k_fwd2d_casc<HLEN, NVD, 4>;
-            else if (W == 8) k = deep ? k_fwd2d_casc<HLEN, HLEN, 8> : k_fwd2d_casc<HLEN, NVD, 8>;
-            else k = deep ? k_fwd2d_casc<HLEN, HLEN, 16> : k_fwd2d_casc<HLEN, NVD, 16>;
+            k = (W == 4) ? k_fwd2d_casc<HLEN, NVD, 4> : (W == 8) ? k_fwd2d_casc<HLEN, NVD, 8> : k_fwd2d_casc<HLEN, NVD, 16>;
             if (lds > 64 * 1024) PDWT_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             PDWT_LAUNCH_KT(kt, k, grid, dim3(64 * W), lds, in, b, nr, nc, VL, trash, cm, f);
             PDWT_CHECK_LAUNCH();
