@@ -208,8 +208,18 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
     g.manual_seed(1234 + rank)
     img = torch.rand(cfg["Nr"], cfg["Nc"], device="cuda", dtype=tdt, generator=g) * 255.0
     torch.cuda.synchronize()
-    W = pdwt_amd_mod().Wavelets(None, cfg["wname"], cfg["levels"], do_swt=cfg["do_swt"], ndim=cfg["ndim"], dtype=cfg["dtype"],
-                                shape=(cfg["Nr"], cfg["Nc"]), device_ptr=img.data_ptr())
+    B = None
+    if world > 1:
+        # N > 1: the batch split of the product (pdwt_amd/batch.py).  The global batch is `world` x this config's per-GPU block
+        # (whole images, or rows of the batched-1D array: shard_rows(world * Nr, world, rank) = Nr rows each); every rank
+        # transforms its own shard with a private Wavelets on its own GPU, no data-path collective.
+        from pdwt_amd.batch import ShardedBatch, shard_rows
+        assert shard_rows(world * cfg["Nr"], world, rank) == (rank * cfg["Nr"], cfg["Nr"])
+        B = ShardedBatch(img, cfg["wname"], cfg["levels"], ndim=cfg["ndim"], do_swt=cfg["do_swt"])
+        W = B.W
+    else:
+        W = pdwt_amd_mod().Wavelets(None, cfg["wname"], cfg["levels"], do_swt=cfg["do_swt"], ndim=cfg["ndim"], dtype=cfg["dtype"],
+                                    shape=(cfg["Nr"], cfg["Nc"]), device_ptr=img.data_ptr())
     assert W.state == pdwt_amd_mod().W_INIT, "Wavelets creation failed"
     levels_eff = W.info.nlevels
 
@@ -283,6 +293,14 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
     del S
     rt_err = float(np.abs(out.astype(np.float64) - ref).max() / np.abs(ref).max())
     sanity["roundtrip_max_rel_err"] = rt_err
+    sanity["roundtrip_mean_rel_err"] = float(np.abs(out.astype(np.float64) - ref).mean() / np.abs(ref).max())
+    if B is not None:
+        # untimed check of the one exchange step of the N > 1 path: norm1() = all-reduce(SUM) of one double per rank (RCCL)
+        W.forward()
+        n_all, parts = B.norm1(), B.norm1_per_rank()
+        sanity["norm1_allreduce_rel_err"] = abs(sum(parts) - n_all) / n_all
+        sanity["norm1_ranks"] = len(parts)
+        W.inverse()
 
     pixels = cfg["Nr"] * cfg["Nc"]
     ms_per_step = elapsed / steps * 1e3

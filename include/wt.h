@@ -46,6 +46,13 @@ int w_ilog2(int i);
 void w_div2(int* N);
 void w_swap_ptr(DTYPE** a, DTYPE** b);
 
+/* Devices (the reference has no multi-GPU support, TODO.txt:15).  An instance lives on the device that is current when it
+ * is constructed -- select it with w_set_device() first -- and every method switches to that device for its duration, so
+ * one host thread can drive instances on several GPUs in turn (see wt_batch.h for the batch split built on this). */
+int w_set_device(int dev);   /* 0 on success */
+int w_get_device(void);
+int w_device_count(void);
+
 /* life cycle of an instance; guards e.g. a second inverse() (band 0 is consumed by the first) */
 typedef enum w_state {
     W_INIT,            /* constructed / image replaced, coefficients not computed */

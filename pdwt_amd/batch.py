@@ -37,7 +37,9 @@ class ShardedBatch:
 
             def engine_factory(a):
                 return pdwt_amd.Wavelets(a, wname, levels, do_swt=do_swt, ndim=ndim)
-        self.W = engine_factory(np.ascontiguousarray(local_rows))
+        # device tensors (torch, or anything with __cuda_array_interface__) go to the engine as they are: memisonhost = 0
+        on_device = hasattr(local_rows, "is_cuda") or hasattr(local_rows, "__cuda_array_interface__")
+        self.W = engine_factory(local_rows if on_device else np.ascontiguousarray(local_rows))
 
     def forward(self):
         self.W.forward()
@@ -58,6 +60,19 @@ class ShardedBatch:
         t = torch.tensor([local], dtype=torch.float64, device=dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return float(t.item())
+
+    def norm1_per_rank(self):
+        """The per-shard partial sums of norm1(), in rank order, on every rank (all-gather of one float64 each): what the
+        all-reduce of norm1() must add up to -- used by bench.py's untimed check of the N > 1 path."""
+        import torch
+        local = float(self.W.norm1_f64())
+        if self.world == 1:
+            return [local]
+        dev = "cuda" if self.dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor([local], dtype=torch.float64, device=dev)
+        outs = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t, group=self.group)
+        return [float(o.item()) for o in outs]
 
     def gather_image(self, dst=0):
         """All shards' reconstructed rows stacked in rank order on rank `dst` (None elsewhere)."""

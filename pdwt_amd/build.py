@@ -88,9 +88,11 @@ def build_demo(force=False):
     """The drop-in acceptance program (examples/demo.cpp) against include/wt.h + libpdwt.so / libpdwtd.so."""
     src = os.path.join(ROOT, "examples", "demo.cpp")
     outs = []
-    for name, lib, flags in (("demo", "pdwt", []), ("demod", "pdwtd", ["-DDOUBLEPRECISION"])):
+    bsrc = os.path.join(ROOT, "examples", "batch_demo.cpp")
+    for name, lib, flags, src in (("demo", "pdwt", [], src), ("demod", "pdwtd", ["-DDOUBLEPRECISION"], src),
+                                  ("batch_demo", "pdwt", [], bsrc), ("batch_demod", "pdwtd", ["-DDOUBLEPRECISION"], bsrc)):
         out = os.path.join(LIB, name)
-        if force or _newer([src, os.path.join(INC, "wt.h"), os.path.join(LIB, "lib%s.so" % lib)], out):
+        if force or _newer([src, os.path.join(INC, "wt.h"), os.path.join(INC, "wt_batch.h"), os.path.join(LIB, "lib%s.so" % lib)], out):
             _run(["g++", "-O2", "-std=c++17", "-Wall"] + flags + ["-I" + INC, src, "-L" + LIB, "-l" + lib, "-lpdwt_hip",
                   "-Wl,-rpath,$ORIGIN", "-o", out])
         outs.append(out)

@@ -61,9 +61,32 @@ struct wstate_t {
     DTYPE* d_k2i;  // inverse
     void* graph[2];  // recorded launches of forward() / inverse() (PDWT_GRAPH=1), NULL until first use
     int graph_off;   // capture failed once for this instance: plain launches from then on
+    int dev;         // the device the instance lives on: the one current when it was constructed (w_set_device / pdwt_set_device)
 };
 static inline filters_t* F(void* p) { return &((wstate_t*)p)->f; }
 static inline wstate_t* WS(void* p) { return (wstate_t*)p; }
+
+// Multi-device use from one host thread (the reference has none: TODO.txt:15): an instance belongs to the device that was
+// current at its construction; every method that touches device memory switches to that device for its duration, so
+// instances on different devices can be driven in turn (their work overlaps: launches are asynchronous).
+struct DevScope {
+    int prev, mine;
+    explicit DevScope(const void* st) : prev(-1), mine(st ? ((const wstate_t*)st)->dev : -1)
+    {
+        if (mine < 0) return;
+        prev = pdwt_get_device();
+        if (prev != mine) pdwt_set_device(mine);
+    }
+    ~DevScope()
+    {
+        if (mine >= 0 && prev >= 0 && prev != mine) pdwt_set_device(prev);
+    }
+};
+#define ON_MY_DEVICE() DevScope dev_scope_(filters_)
+
+int w_set_device(int dev) { return pdwt_set_device(dev); }
+int w_get_device(void) { return pdwt_get_device(); }
+int w_device_count(void) { return pdwt_device_count(); }
 
 static void report(const char* where, int rc)
 {
@@ -124,6 +147,7 @@ Wavelets::Wavelets(DTYPE* img, int Nr, int Nc, const char* wname_, int levels, i
 
     // filters: per-instance copy of the bank
     filters_ = calloc(1, sizeof(wstate_t));
+    if (filters_) WS(filters_)->dev = pdwt_get_device();
     filters_t* fb = filters_ ? F(filters_) : NULL;
     int hlen = fb ? SFX(pdwt_compute_filters_separable)(this->wname, do_swt, fb) : 0;
     if (hlen <= 0) {
@@ -179,10 +203,12 @@ Wavelets::Wavelets(const Wavelets& W)
       do_separable(W.do_separable), do_cycle_spinning(W.do_cycle_spinning), winfos(W.winfos), state(W.state), filters_(NULL)
 {
     memcpy(wname, W.wname, sizeof(wname));
+    DevScope dev_scope_(W.filters_);  // the copy lives on the source's device
     if (W.filters_) {
         filters_ = calloc(1, sizeof(wstate_t));
         if (filters_) {
             *F(filters_) = *F(W.filters_);
+            WS(filters_)->dev = WS(W.filters_)->dev;
             const size_t nb = 4 * (size_t)winfos.hlen * winfos.hlen * sizeof(DTYPE);
             for (int d = 0; d < 2; d++) {  // deep copy of the custom 2-D kernels
                 DTYPE* src = d ? WS(W.filters_)->d_k2i : WS(W.filters_)->d_k2f;
@@ -215,6 +241,7 @@ Wavelets::Wavelets(const Wavelets& W)
 static void drop_graphs(void* st);
 Wavelets::~Wavelets()
 {
+    ON_MY_DEVICE();
     if (d_image) pdwt_free(d_image);
     if (d_coeffs) SFX(pdwt_free_coeffs_buffer)(d_coeffs, to_pdwt(winfos));
     if (d_tmp) pdwt_free(d_tmp);
@@ -284,6 +311,7 @@ static int run_graphed(void* st, int dir, bool eligible, F enqueue)
 
 void Wavelets::forward()
 {
+    ON_MY_DEVICE();
     if (state == W_CREATION_ERROR) {
         puts("Warning: forward transform not computed, as there was an error when creating the wavelets");
         return;
@@ -323,6 +351,7 @@ void Wavelets::forward()
 
 void Wavelets::inverse()
 {
+    ON_MY_DEVICE();
     if (state == W_INVERSE) {
         puts("Warning: W.inverse() has already been run. Inverse is available in W.get_image()");
         return;
@@ -368,6 +397,7 @@ void Wavelets::inverse()
 // ---- coefficient utilities -----------------------------------------------------------------------
 void Wavelets::soft_threshold(DTYPE beta, int do_thresh_appcoeffs, int normalize)
 {
+    ON_MY_DEVICE();
     if (state == W_INVERSE) {
         puts("Warning: Wavelets(): cannot threshold coefficients, as they were modified by W.inverse()");
         return;
@@ -382,6 +412,7 @@ void Wavelets::soft_threshold(DTYPE beta, int do_thresh_appcoeffs, int normalize
 
 DTYPE Wavelets::norm1()
 {
+    ON_MY_DEVICE();
     if (state == W_CREATION_ERROR) return 0;
     DTYPE res = 0;
     int rc = SFX(pdwt_norm1)(d_coeffs, to_pdwt(winfos), &res);
@@ -405,24 +436,29 @@ DTYPE Wavelets::norm1()
     }
 void Wavelets::hard_threshold(DTYPE beta, int do_thresh_appcoeffs, int normalize)
 {
+    ON_MY_DEVICE();
     PDWT_THRESH_METHOD("hard_threshold", SFX(pdwt_hard_thresh)(d_coeffs, beta, to_pdwt(winfos), do_thresh_appcoeffs, normalize))
 }
 void Wavelets::group_soft_threshold(DTYPE beta, int do_thresh_appcoeffs, int normalize)
 {
+    ON_MY_DEVICE();
     PDWT_THRESH_METHOD("group_soft_threshold", SFX(pdwt_group_soft_thresh)(d_coeffs, beta, to_pdwt(winfos), do_thresh_appcoeffs, normalize))
 }
 void Wavelets::shrink(DTYPE beta, int do_thresh_appcoeffs)
 {
+    ON_MY_DEVICE();
     PDWT_THRESH_METHOD("shrink", SFX(pdwt_shrink)(d_coeffs, beta, to_pdwt(winfos), do_thresh_appcoeffs))
 }
 void Wavelets::proj_linf(DTYPE beta, int do_thresh_appcoeffs)
 {
+    ON_MY_DEVICE();
     PDWT_THRESH_METHOD("proj_linf", SFX(pdwt_proj_linf)(d_coeffs, beta, to_pdwt(winfos), do_thresh_appcoeffs))
 }
 
 // src/wt.cu:364-366: if inplace = 1 the result is in d_image, otherwise in d_tmp
 void Wavelets::circshift(int sr, int sc, int inplace)
 {
+    ON_MY_DEVICE();
     if (state == W_CREATION_ERROR || !d_image || !d_tmp) return;
     const int rc = SFX(pdwt_circshift)(d_image, d_tmp, to_pdwt(winfos), sr, sc, inplace);
     if (rc != PDWT_OK) report("Wavelets::circshift()", rc);
@@ -430,6 +466,7 @@ void Wavelets::circshift(int sr, int sc, int inplace)
 
 DTYPE Wavelets::norm2sq()
 {
+    ON_MY_DEVICE();
     if (state == W_CREATION_ERROR) return 0;
     DTYPE res = 0;
     const int rc = SFX(pdwt_norm2sq)(d_coeffs, to_pdwt(winfos), &res);
@@ -457,6 +494,7 @@ static DTYPE* upload_k2(DTYPE* f1, DTYPE* f2, DTYPE* f3, DTYPE* f4, unsigned len
 
 int Wavelets::set_filters_forward(char* filtername, uint len, DTYPE* filter1, DTYPE* filter2, DTYPE* filter3, DTYPE* filter4)
 {
+    ON_MY_DEVICE();
     if (len > PDWT_MAX_FILTER_WIDTH) {
         printf("ERROR: Wavelets.set_filters_forward(): filter length (%d) exceeds the maximum size (%d)\n", (int)len, PDWT_MAX_FILTER_WIDTH);
         return -1;
@@ -495,6 +533,7 @@ int Wavelets::set_filters_forward(char* filtername, uint len, DTYPE* filter1, DT
 // the inverse filters are assumed to have the length given to set_filters_forward() (src/wt.cu:584-602)
 int Wavelets::set_filters_inverse(DTYPE* filter1, DTYPE* filter2, DTYPE* filter3, DTYPE* filter4)
 {
+    ON_MY_DEVICE();
     if (!filter1 || !filter2 || !filters_) return -2;
     drop_graphs(filters_);
     const int len = winfos.hlen;
@@ -521,6 +560,7 @@ int Wavelets::set_filters_inverse(DTYPE* filter1, DTYPE* filter2, DTYPE* filter3
 // (deep copy) as in the reference header.
 int Wavelets::add_wavelet(Wavelets W, DTYPE alpha)
 {
+    ON_MY_DEVICE();
     if ((winfos.nlevels != W.winfos.nlevels) || (strcasecmp(wname, W.wname))) {
         puts("ERROR: add_wavelet(): right operand is not the same transform (wname, level)");
         return -1;
@@ -554,6 +594,7 @@ int Wavelets::add_wavelet(Wavelets W, DTYPE alpha)
 // ---- data movement ---------------------------------------------------------------------------------
 int Wavelets::get_image(DTYPE* res)
 {
+    ON_MY_DEVICE();
     if (!d_image || !res) return 0;
     const size_t n = (size_t)winfos.Nr * winfos.Nc;
     if (pdwt_memcpy_d2h(res, d_image, n * sizeof(DTYPE)) != PDWT_OK) return 0;
@@ -562,6 +603,7 @@ int Wavelets::get_image(DTYPE* res)
 
 void Wavelets::set_image(DTYPE* img, int mem_is_on_device)
 {
+    ON_MY_DEVICE();
     if (!d_image || !img) return;
     const size_t nb = (size_t)winfos.Nr * winfos.Nc * sizeof(DTYPE);
     int rc = mem_is_on_device ? pdwt_memcpy_d2d_foreign(d_image, img, nb) : pdwt_memcpy_h2d(d_image, img, nb);
@@ -577,6 +619,7 @@ static long long band_elems(const w_info& w, int num)
 
 void Wavelets::set_coeff(DTYPE* coeff, int num, int mem_is_on_device)
 {
+    ON_MY_DEVICE();
     if (!d_coeffs || !coeff) return;
     const long long n = band_elems(winfos, num);
     if (n <= 0) {
@@ -590,6 +633,7 @@ void Wavelets::set_coeff(DTYPE* coeff, int num, int mem_is_on_device)
 
 int Wavelets::get_coeff(DTYPE* coeff, int num)
 {
+    ON_MY_DEVICE();
     if (state == W_INVERSE) {
         puts("Warning: get_coeff(): inverse() has been performed, the coefficients has been modified and do not make sense anymore.");
         return 0;
@@ -606,6 +650,7 @@ int Wavelets::get_coeff(DTYPE* coeff, int num)
 
 void Wavelets::print_informations()
 {
+    ON_MY_DEVICE();
     const char* yn[2] = {"no", "yes"};
     puts("------------- Wavelet transform infos ------------");
     printf("Data dimensions : ");

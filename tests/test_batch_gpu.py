@@ -1,0 +1,112 @@
+"""N > 1 product path on real hardware: ShardedBatch with the DEFAULT engine (pdwt_amd.Wavelets on the rank's GPU).
+
+  * two ranks on ONE GPU over gloo (runs on the 1-GPU test box): per-rank Wavelets instances of two processes share the
+    device, the norm1 partials are all-reduced, the gathered result equals the unsharded GPU run bit for bit (rows are
+    independent signals) and the oracle within tolerance;
+  * two ranks on two GPUs over nccl (= RCCL over xGMI) when the box has >= 2 devices, skipped otherwise.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, backend, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    import pdwt_amd
+    from pdwt_amd.batch import ShardedBatch, shard_rows
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    assert pdwt_amd.hip().pdwt_set_device(dev) == 0
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x = np.random.RandomState(1).randn(37, 4096).astype(np.float32)  # 37 rows: uneven split 19 + 18
+        s, n = shard_rows(x.shape[0], world, rank)
+        xs = torch.from_numpy(x[s:s + n]).cuda()  # the shard lives in HBM: memisonhost = 0
+        B = ShardedBatch(xs, "sym8", 4, ndim=1)   # default engine: pdwt_amd.Wavelets on this rank's GPU
+        B.forward()
+        n1 = B.norm1()
+        parts = B.norm1_per_rank()
+        B.soft_threshold(0.25)
+        n1t = B.norm1()
+        B.inverse()
+        img = B.gather_image(0)
+        if rank == 0:
+            q.put((n1, parts, n1t, img))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(backend):
+    import torch.multiprocessing as mp
+    import pdwt_amd
+    from oracle import oracle as orc
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n1, parts, n1t, img = q.get(timeout=280)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    x = np.random.RandomState(1).randn(37, 4096).astype(np.float32)
+    # unsharded run on this GPU: identical rows -> identical bits
+    W = pdwt_amd.Wavelets(x, "sym8", 4, ndim=1)
+    W.forward()
+    ref1 = W.norm1_f64()
+    assert abs(n1 - ref1) <= 1e-12 * ref1 and abs(sum(parts) - n1) <= 1e-12 * ref1 and len(parts) == 2
+    W.soft_threshold(0.25)
+    assert abs(n1t - W.norm1_f64()) <= 1e-12 * ref1
+    W.inverse()
+    assert np.array_equal(img, W.get_image())
+    O = orc.OracleWavelets(x, "sym8", 4, ndim=1)
+    O.forward()
+    assert abs(n1 - O.norm1_f64()) <= 1e-6 * O.norm1_f64()
+    O.soft_threshold(0.25)
+    O.inverse()
+    assert np.abs(img - O.get_image()).max() <= 1e-5 * np.abs(x).max()
+
+
+@pytest.mark.timeout(400)
+def test_two_ranks_default_engine_one_gpu_gloo():
+    _run("gloo")
+
+
+@pytest.mark.timeout(400)
+def test_two_ranks_default_engine_nccl():
+    import pdwt_amd
+    if pdwt_amd.hip().pdwt_device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL over xGMI)")
+    _run("nccl")
+
+
+@pytest.mark.parametrize("exe,shards", [("batch_demo", 3), ("batch_demod", 2), ("batch_demo", 8)])
+def test_one_process_batch_split_cpp(exe, shards):
+    """include/wt_batch.h: the batch split driven from ONE host process through the C++ class (an instance per shard on
+    device s % ndev, every method switches to its instance's device) equals the unsharded run."""
+    import subprocess
+    r = subprocess.run([os.path.join(ROOT, "pdwt_amd", "lib", exe), "37", "2048", "sym8", "4", str(shards)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "batch OK" in r.stdout, r.stdout + r.stderr
