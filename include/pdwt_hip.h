@@ -197,6 +197,16 @@ int pdwt_soft_thresh_f32(float** d_coeffs, float beta, pdwt_info info, int do_th
 int pdwt_soft_thresh_f64(double** d_coeffs, double beta, pdwt_info info, int do_thresh_appcoeffs, int normalize);
 int pdwt_norm1_f32(float** d_coeffs, pdwt_info info, float* out);
 int pdwt_norm1_f64(double** d_coeffs, pdwt_info info, double* out);
+/* Threshold and norm in ONE pass over the bands: soft_thresh as above and, as a by-product, sum |c| over ALL bands (the
+ * approximation band included, thresholded or not) of the thresholded coefficients -- what pdwt_norm1 would return right
+ * after.  `d_scratch`: device buffer of pdwt_sum_scratch_doubles() doubles, zero-filled ONCE by the caller
+ * (pdwt_memset) and then reusable for any number of calls on the library stream; no host synchronisation.
+ * pdwt_sum_scratch_read copies the result out (synchronises the stream).  The block partials are added in a fixed
+ * order by the last block to finish: run-to-run deterministic. */
+size_t pdwt_sum_scratch_doubles(void);
+int pdwt_soft_thresh_sum_f32(float** d_coeffs, float beta, pdwt_info info, int do_thresh_appcoeffs, int normalize, double* d_scratch);
+int pdwt_soft_thresh_sum_f64(double** d_coeffs, double beta, pdwt_info info, int do_thresh_appcoeffs, int normalize, double* d_scratch);
+int pdwt_sum_scratch_read(const double* d_scratch, double* out);
 /* same reduction, result in double regardless of T (used to combine shards across GPUs) */
 int pdwt_norm1_as_double_f32(float** d_coeffs, pdwt_info info, double* out);
 int pdwt_norm1_as_double_f64(double** d_coeffs, pdwt_info info, double* out);

@@ -69,7 +69,10 @@ class Wavelets {
   public:
     /* data members: order and types of src/wt.h:24-34 */
     DTYPE* d_image;        /* device: input image / reconstruction */
-    DTYPE** d_coeffs;      /* host array of device pointers: [A, H1,V1,D1, ...] or [A, D1, ...] */
+    DTYPE** d_coeffs;      /* host array of device pointers: [A, H1,V1,D1, ...] or [A, D1, ...].  A caller that WRITES a band
+                              through these pointers must call coeff_int_ptr() once first (any index): soft_threshold() keeps
+                              sum|c| for the norm1() that follows it, and only coeff_int_ptr()/set_coeff() tell the class that
+                              the bands may change behind its back */
     DTYPE* d_tmp;          /* device scratch */
     int current_shift_r;
     int current_shift_c;

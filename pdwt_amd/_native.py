@@ -39,9 +39,10 @@ PLAIN_SYMBOLS = ["pdwt_device_count", "pdwt_set_device", "pdwt_get_device", "pdw
                  "pdwt_last_error_string", "pdwt_event_create", "pdwt_event_record", "pdwt_event_sync", "pdwt_event_elapsed_ms",
                  "pdwt_event_destroy", "pdwt_ktime_enable", "pdwt_ktime_reset", "pdwt_ktime_read", "pdwt_kernel_name",
                  "pdwt_kernel_count", "pdwt_graph_allowed", "pdwt_graph_capture_begin", "pdwt_graph_capture_end", "pdwt_graph_launch",
-                 "pdwt_graph_destroy", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set", "pdwt_debug_get"]
+                 "pdwt_graph_destroy", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set", "pdwt_debug_get",
+                 "pdwt_sum_scratch_doubles", "pdwt_sum_scratch_read"]
 TYPED_SYMBOLS = (["compute_filters_separable", "create_coeffs_buffer", "free_coeffs_buffer", "copy_coeffs_buffer",
-                  "soft_thresh", "norm1", "norm1_as_double", "hard_thresh", "proj_linf", "shrink", "group_soft_thresh",
+                  "soft_thresh", "soft_thresh_sum", "norm1", "norm1_as_double", "hard_thresh", "proj_linf", "shrink", "group_soft_thresh",
                   "norm2sq", "norm2sq_as_double", "add_coeffs", "circshift", "forward_nonseparable", "inverse_nonseparable",
                   "forward_swt_nonseparable", "inverse_swt_nonseparable"] + DRIVERS + HAAR_DRIVERS)
 
@@ -139,6 +140,8 @@ def host(dtype):
         L.pdwt_wavelets_soft_threshold.argtypes = [vp, ct, ci, ci]
         L.pdwt_wavelets_norm1.restype = ct
         L.pdwt_wavelets_norm1.argtypes = [vp]
+        L.pdwt_wavelets_norm1_f64.restype = C.c_double
+        L.pdwt_wavelets_norm1_f64.argtypes = [vp]
         L.pdwt_wavelets_norm2sq.restype = ct
         L.pdwt_wavelets_norm2sq.argtypes = [vp]
         for n in ("hard_threshold", "group_soft_threshold"):

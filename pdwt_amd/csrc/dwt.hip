@@ -507,8 +507,7 @@ static int launch_ana_cols(const T* t1, const T* t2, T* cA, T* cH, T* cV, T* cD,
 {
     if (!tiled_cols_forced()) {  // register-ring kernels (cols_ring.inc): one launch per branch
         KTimer kt(K_ANA_COLS);
-        int rc = ana_cols_ring<T>(t1, cA, cH, Nr, Ncw, hlen, f);
-        if (rc == PDWT_OK) rc = ana_cols_ring<T>(t2, cV, cD, Nr, Ncw, hlen, f);
+        const int rc = ana_cols_ring<T>(t1, cA, cH, Nr, Ncw, hlen, f, t2, cV, cD);  // both branches in one launch
         if (rc <= 0) return rc;
     }
     constexpr int TYO = 16;
@@ -534,8 +533,7 @@ static int launch_syn_cols(const T* cA, const T* cH, const T* cV, const T* cD, T
 {
     if (!tiled_cols_forced()) {
         KTimer kt(K_SYN_COLS);
-        int rc = syn_cols_ring<T>(cA, cH, t1, Nri, Nc, Nro, hlen, f);
-        if (rc == PDWT_OK) rc = syn_cols_ring<T>(cV, cD, t2, Nri, Nc, Nro, hlen, f);
+        const int rc = syn_cols_ring<T>(cA, cH, t1, Nri, Nc, Nro, hlen, f, cV, cD, t2);  // both branches in one launch
         if (rc <= 0) return rc;
     }
     constexpr int TYC = 16;

@@ -113,6 +113,115 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Soft threshold that also leaves  sum |c|  over ALL bands of the table (after the threshold) behind: the norm1() that
+// usually follows a threshold (reference call sequence: soft_threshold -> norm1, src/demo.cpp:203-205, and every
+// proximal-gradient loop built on the class) then costs one 8-byte copy instead of a second pass over every band.
+// Bands with beta < 0 are only summed (the approximation band when it is not thresholded).
+// scratch: [0, kMaxBlocks) per-block partials, [kMaxBlocks] result, [kMaxBlocks+1] arrival counter (as double bits are
+// not used: the counter lives in the first 4 bytes).  The LAST block to arrive adds the partials in a fixed order, so the
+// result does not depend on the order in which blocks finish.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kUThreads) void k_soft_thresh_sum(BandTable<T> tab, double* __restrict__ scratch)
+{
+    __shared__ double s_w[kUThreads / 64];
+    __shared__ int s_last;
+    constexpr int NVV = VEC ? V16<T>::N : 1;
+    constexpr int U = kChunk / (kUThreads * NVV);
+    double accs[VEC ? U : 1];  // one partial per unrolled position: independent add chains, all loads of a chunk in flight together
+#pragma unroll
+    for (int u = 0; u < (VEC ? U : 1); u++) accs[u] = 0.0;
+    const unsigned int total = tab.chunk0[tab.nb];
+    for (unsigned int chunk = blockIdx.x; chunk < total; chunk += gridDim.x) {
+        const int k = find_band(tab.chunk0, tab.nb, chunk);
+        T* __restrict__ p = tab.ptr[k];
+        const unsigned long long n = tab.n[k];
+        const T beta = tab.beta[k];
+        const bool modify = !(beta < T(0));
+        const T beta_eff = modify ? beta : T(0);  // soft threshold with beta = 0 is the identity: one code path, stores predicated
+        const unsigned long long base = (unsigned long long)(chunk - tab.chunk0[k]) * kChunk;
+        if constexpr (VEC) {
+            using V = typename V16<T>::type;
+            constexpr int NV = V16<T>::N;
+            if (base + kChunk <= n) {  // full chunk: no bounds checks, every load issued before the first use
+                V v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) v[u] = *reinterpret_cast<const V*>(p + base + ((unsigned long long)u * kUThreads + threadIdx.x) * NV);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    T* e = reinterpret_cast<T*>(&v[u]);
+                    double a = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NV; q++) {
+                        e[q] = ew_op<OP_SOFT, T>(e[q], beta_eff);
+                        a += (double)abs_t(e[q]);
+                    }
+                    accs[u] += a;
+                    if (modify) *reinterpret_cast<V*>(p + base + ((unsigned long long)u * kUThreads + threadIdx.x) * NV) = v[u];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const unsigned long long i = base + ((unsigned long long)u * kUThreads + threadIdx.x) * NV;
+                    if (i + NV <= n) {
+                        V v = *reinterpret_cast<V*>(p + i);
+                        T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+                        for (int q = 0; q < NV; q++) {
+                            e[q] = ew_op<OP_SOFT, T>(e[q], beta_eff);
+                            accs[u] += (double)abs_t(e[q]);
+                        }
+                        if (modify) *reinterpret_cast<V*>(p + i) = v;
+                    } else {
+                        for (unsigned long long j = i; j < n; j++) {
+                            const T x = ew_op<OP_SOFT, T>(p[j], beta_eff);
+                            if (modify) p[j] = x;
+                            accs[u] += (double)abs_t(x);
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int u = 0; u < kChunk / kUThreads; u++) {
+                const unsigned long long i = base + (unsigned long long)u * kUThreads + threadIdx.x;
+                if (i < n) {
+                    const T x = ew_op<OP_SOFT, T>(p[i], beta_eff);
+                    if (modify) p[i] = x;
+                    accs[0] += (double)abs_t(x);
+                }
+            }
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < (VEC ? U : 1); u++) acc += accs[u];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // publish the partial WITHOUT a release fence: an agent-scope release (buffer_wbl2) would write back every dirty line
+        // of this XCD's L2 -- i.e. the thresholded coefficients all blocks have just stored -- once per block (measured: 306 us
+        // instead of 190).  A write-through (agent-scope atomic) store, drained before the ticket is taken, orders the two.
+        __hip_atomic_store(scratch + blockIdx.x, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int ticket = __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(scratch + kMaxBlocks + 1), 1u, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (ticket == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (s_last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 only; the partials are read past it (agent-scope loads)
+        double a = 0.0;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += kUThreads) a += __hip_atomic_load(scratch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a = wave_sum(a);
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            scratch[kMaxBlocks] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+            __hip_atomic_store(reinterpret_cast<unsigned int*>(scratch + kMaxBlocks + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+        }
+    }
+}
+
 template <typename T, bool VEC>
 __global__ __launch_bounds__(kUThreads) void k_abs_sum(BandTable<T> tab, double* __restrict__ partial)
 {
@@ -342,6 +451,49 @@ static int ew_bands(T** c, T beta, pdwt_info w, int do_thresh_appcoeffs, int nor
     return PDWT_OK;
 }
 
+// soft threshold + sum|c| of the result over all bands in `scratch` (device, pdwt_sum_scratch_doubles() doubles,
+// zero-initialised once by the caller); nothing is copied to the host and nothing synchronises
+template <typename T>
+static int soft_thresh_sum(T** c, T beta, pdwt_info w, int do_thresh_appcoeffs, int normalize, double* scratch)
+{
+    if (!c || !scratch) return PDWT_EINVAL;
+    BandGeom g;
+    if (band_geometry(w, &g) != PDWT_OK) return PDWT_EINVAL;
+    BandTable<T> tab;
+    tab.nb = 0;
+    tab.chunk0[0] = 0;
+    bool vec = true;
+    const int per = (w.ndims == 2) ? 3 : 1;
+    {
+        T beta2 = T(-1);  // band 0: summed only, unless the approximation is thresholded too
+        if (do_thresh_appcoeffs) {
+            beta2 = beta;
+            if (normalize > 0) {  // beta / sqrt(2)^nlevels, src/common.cu:231-235
+                const int nl2 = w.nlevels / 2;
+                beta2 /= (T)(1 << nl2);
+                if (nl2 * 2 != w.nlevels) beta2 = (T)(beta2 / 1.4142135623730951);
+            }
+            if (beta2 < T(0)) beta2 = T(0);
+        }
+        if (!table_push<T>(tab, c[0], (size_t)g.Nr[0] * g.Nc[0], beta2, vec)) return PDWT_EINVAL;
+    }
+    if (beta < T(0)) return PDWT_EINVAL;  // (a negative threshold means "sum only" inside the kernel)
+    for (int lev = 0; lev < w.nlevels; lev++) {
+        if (normalize > 0) beta = (T)(beta / 1.4142135623730951);  // src/common.cu:244
+        for (int b = 0; b < per; b++) {
+            const int k = per * lev + 1 + b;
+            if (!table_push<T>(tab, c[k], (size_t)g.Nr[k] * g.Nc[k], beta, vec)) return PDWT_EINVAL;
+        }
+    }
+    const unsigned int total = tab.chunk0[tab.nb];
+    const int blocks = (int)(total < (unsigned)kMaxBlocks ? (total ? total : 1) : (unsigned)kMaxBlocks);
+    KTimer kt(K_THRESH_SUM);
+    if (vec) hipLaunchKernelGGL((k_soft_thresh_sum<T, true>), dim3(blocks), dim3(kUThreads), 0, stream(), tab, scratch);
+    else hipLaunchKernelGGL((k_soft_thresh_sum<T, false>), dim3(blocks), dim3(kUThreads), 0, stream(), tab, scratch);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
 // w_call_group_soft_thresh, src/common.cu:318-343
 template <typename T>
 static int group_soft_thresh(T** c, T beta, pdwt_info w, int do_thresh_appcoeffs, int normalize)
@@ -501,10 +653,20 @@ using namespace pdwt;
         if (rc == PDWT_OK) *out = (T)d;                                                                                                      \
         return rc;                                                                                                                           \
     }                                                                                                                                        \
+    int pdwt_soft_thresh_sum_##SFX(T** c, T beta, pdwt_info w, int app, int norm, double* scratch)                                         \
+    {                                                                                                                                        \
+        return soft_thresh_sum<T>(c, beta, w, app, norm, scratch);                                                                           \
+    }                                                                                                                                        \
     int pdwt_add_coeffs_##SFX(T** dst, T** src, pdwt_info w, T alpha) { return add_coeffs<T>(dst, src, w, alpha); }                         \
     int pdwt_circshift_##SFX(T* img, T* img2, pdwt_info w, int sr, int sc, int inplace) { return circshift<T>(img, img2, w, sr, sc, inplace); }
 
 extern "C" {
+size_t pdwt_sum_scratch_doubles(void) { return (size_t)kMaxBlocks + 8; }
+int pdwt_sum_scratch_read(const double* scratch, double* out)
+{
+    if (!scratch || !out) return PDWT_EINVAL;
+    return pdwt_memcpy_d2h(out, scratch + kMaxBlocks, sizeof(double));
+}
 PDWT_UTILS_API(f32, float)
 PDWT_UTILS_API(f64, double)
 }

@@ -62,7 +62,17 @@ struct wstate_t {
     void* graph[2];  // recorded launches of forward() / inverse() (PDWT_GRAPH=1), NULL until first use
     int graph_off;   // capture failed once for this instance: plain launches from then on
     int dev;         // the device the instance lives on: the one current when it was constructed (w_set_device / pdwt_set_device)
+    // norm1 bookkeeping: soft_threshold() leaves sum|c| of the thresholded bands in d_sum (one pass instead of two); norm1()
+    // returns it as long as nothing has touched the coefficients since (sum_valid).  Handing out a raw band pointer
+    // (coeff_int_ptr) switches the bookkeeping off for good: the caller may then write the bands behind the class's back.
+    double* d_sum;
+    int sum_valid;
+    int raw_ptr_taken;
 };
+static inline void coeffs_changed(void* st)
+{
+    if (st) ((wstate_t*)st)->sum_valid = 0;
+}
 static inline filters_t* F(void* p) { return &((wstate_t*)p)->f; }
 static inline wstate_t* WS(void* p) { return (wstate_t*)p; }
 
@@ -209,6 +219,7 @@ Wavelets::Wavelets(const Wavelets& W)
         if (filters_) {
             *F(filters_) = *F(W.filters_);
             WS(filters_)->dev = WS(W.filters_)->dev;
+            WS(filters_)->raw_ptr_taken = WS(W.filters_)->raw_ptr_taken;  // (d_sum / sum_valid stay 0: the copy starts without a cached norm)
             const size_t nb = 4 * (size_t)winfos.hlen * winfos.hlen * sizeof(DTYPE);
             for (int d = 0; d < 2; d++) {  // deep copy of the custom 2-D kernels
                 DTYPE* src = d ? WS(W.filters_)->d_k2i : WS(W.filters_)->d_k2f;
@@ -249,6 +260,7 @@ Wavelets::~Wavelets()
     if (filters_) {
         if (WS(filters_)->d_k2f) pdwt_free(WS(filters_)->d_k2f);
         if (WS(filters_)->d_k2i) pdwt_free(WS(filters_)->d_k2i);
+        if (WS(filters_)->d_sum) pdwt_free(WS(filters_)->d_sum);
     }
     free(filters_);
 }
@@ -321,6 +333,7 @@ void Wavelets::forward()
         current_shift_c = rand() % winfos.Nc;
         circshift(current_shift_r, current_shift_c, 1);
     }
+    coeffs_changed(filters_);
     const pdwt_info w = to_pdwt(winfos);
     const bool haar = (winfos.hlen == 2) && !winfos.do_swt;  // dedicated 2-tap kernels
     DTYPE* swapped[3 * 32 + 1];
@@ -360,6 +373,7 @@ void Wavelets::inverse()
         puts("Warning: inverse transform not computed, as there was an error in a previous stage");
         return;
     }
+    coeffs_changed(filters_);  // inverse() consumes band 0
     const pdwt_info w = to_pdwt(winfos);
     const bool haar = (winfos.hlen == 2) && !winfos.do_swt;
     DTYPE* swapped[3 * 32 + 1];
@@ -395,6 +409,13 @@ void Wavelets::inverse()
 }
 
 // ---- coefficient utilities -----------------------------------------------------------------------
+// PDWT_NORM_IN_THRESHOLD=0: soft_threshold() never computes the norm on the side (norm1() always reduces the bands)
+static bool norm_in_threshold()
+{
+    static const int on = getenv("PDWT_NORM_IN_THRESHOLD") ? atoi(getenv("PDWT_NORM_IN_THRESHOLD")) : 1;
+    return on == 1;
+}
+
 void Wavelets::soft_threshold(DTYPE beta, int do_thresh_appcoeffs, int normalize)
 {
     ON_MY_DEVICE();
@@ -403,21 +424,56 @@ void Wavelets::soft_threshold(DTYPE beta, int do_thresh_appcoeffs, int normalize
         return;
     }
     if (state == W_CREATION_ERROR) return;
-    int rc = SFX(pdwt_soft_thresh)(d_coeffs, beta, to_pdwt(winfos), do_thresh_appcoeffs, normalize);
+    coeffs_changed(filters_);
+    wstate_t* st = WS(filters_);
+    int rc;
+    if (st && !st->raw_ptr_taken && norm_in_threshold() && !(beta < (DTYPE)0)) {
+        if (!st->d_sum) {
+            const size_t nb = pdwt_sum_scratch_doubles() * sizeof(double);
+            st->d_sum = (double*)pdwt_malloc(nb);
+            if (st->d_sum && pdwt_memset(st->d_sum, 0, nb) != PDWT_OK) {
+                pdwt_free(st->d_sum);
+                st->d_sum = NULL;
+            }
+        }
+        if (st->d_sum) {
+            rc = SFX(pdwt_soft_thresh_sum)(d_coeffs, beta, to_pdwt(winfos), do_thresh_appcoeffs, normalize, st->d_sum);
+            if (rc == PDWT_OK) st->sum_valid = 1;
+        } else {
+            rc = SFX(pdwt_soft_thresh)(d_coeffs, beta, to_pdwt(winfos), do_thresh_appcoeffs, normalize);
+        }
+    } else {
+        rc = SFX(pdwt_soft_thresh)(d_coeffs, beta, to_pdwt(winfos), do_thresh_appcoeffs, normalize);
+    }
     if (rc != PDWT_OK) {
         report("Wavelets::soft_threshold()", rc);
         state = W_THRESHOLD_ERROR;
     }
 }
 
+// the double-precision value behind the last norm1() of this thread (shards of a batch are combined in double: wt_capi.cpp)
+static thread_local double g_last_norm1 = 0.0;
+double w_last_norm1_double(void) { return g_last_norm1; }
+
 DTYPE Wavelets::norm1()
 {
     ON_MY_DEVICE();
     if (state == W_CREATION_ERROR) return 0;
-    DTYPE res = 0;
-    int rc = SFX(pdwt_norm1)(d_coeffs, to_pdwt(winfos), &res);
+    wstate_t* st = WS(filters_);
+    double d = 0;
+    if (st && st->sum_valid && st->d_sum && !st->raw_ptr_taken) {
+        // the last soft_threshold() left sum|c| behind and no method has touched the bands since
+        const int rc = pdwt_sum_scratch_read(st->d_sum, &d);
+        if (rc == PDWT_OK) {
+            g_last_norm1 = d;
+            return (DTYPE)d;
+        }
+        report("Wavelets::norm1()", rc);
+    }
+    int rc = SFX(pdwt_norm1_as_double)(d_coeffs, to_pdwt(winfos), &d);
     if (rc != PDWT_OK) report("Wavelets::norm1()", rc);
-    return res;
+    g_last_norm1 = d;
+    return (DTYPE)d;
 }
 
 // The remaining coefficient utilities (src/wt.cu:320-358): same state rule as soft_threshold.
@@ -427,6 +483,7 @@ DTYPE Wavelets::norm1()
         return;                                                                                                \
     }                                                                                                          \
     if (state == W_CREATION_ERROR) return;                                                                     \
+    coeffs_changed(filters_);                                                                                  \
     {                                                                                                          \
         const int rc = CALL;                                                                                   \
         if (rc != PDWT_OK) {                                                                                   \
@@ -582,6 +639,7 @@ int Wavelets::add_wavelet(Wavelets W, DTYPE alpha)
         return -4;
     }
     if (state == W_CREATION_ERROR || W.state == W_CREATION_ERROR || !d_coeffs || !W.d_coeffs) return -5;
+    coeffs_changed(filters_);
     const int rc = SFX(pdwt_add_coeffs)(d_coeffs, W.d_coeffs, to_pdwt(winfos), alpha);
     if (rc != PDWT_OK) {
         report("Wavelets::add_wavelet()", rc);
@@ -626,6 +684,7 @@ void Wavelets::set_coeff(DTYPE* coeff, int num, int mem_is_on_device)
         printf("ERROR: set_coeff(): invalid coefficient index %d\n", num);
         return;
     }
+    coeffs_changed(filters_);
     const size_t nb = (size_t)n * sizeof(DTYPE);
     int rc = mem_is_on_device ? pdwt_memcpy_d2d_foreign(d_coeffs[num], coeff, nb) : pdwt_memcpy_h2d(d_coeffs[num], coeff, nb);
     if (rc != PDWT_OK) report("Wavelets::set_coeff()", rc);
@@ -676,4 +735,11 @@ void Wavelets::print_informations()
 }
 
 intptr_t Wavelets::image_int_ptr(void) { return (intptr_t)d_image; }
-intptr_t Wavelets::coeff_int_ptr(int num) { return (intptr_t)d_coeffs[num]; }
+intptr_t Wavelets::coeff_int_ptr(int num)
+{
+    if (filters_) {  // the caller may write the band through this pointer: no more norm bookkeeping for this instance
+        WS(filters_)->raw_ptr_taken = 1;
+        WS(filters_)->sum_valid = 0;
+    }
+    return (intptr_t)d_coeffs[num];
+}

@@ -8,6 +8,8 @@
 
 #define W(h) (static_cast<Wavelets*>(h))
 
+double w_last_norm1_double(void);  // wt.cpp: the double behind the calling thread's last norm1()
+
 extern "C" {
 int pdwt_wavelets_sizeof_dtype(void) { return (int)sizeof(DTYPE); }
 
@@ -23,6 +25,12 @@ void pdwt_wavelets_forward(void* h) { W(h)->forward(); }
 void pdwt_wavelets_inverse(void* h) { W(h)->inverse(); }
 void pdwt_wavelets_soft_threshold(void* h, DTYPE beta, int do_thresh_appcoeffs, int normalize) { W(h)->soft_threshold(beta, do_thresh_appcoeffs, normalize); }
 DTYPE pdwt_wavelets_norm1(void* h) { return W(h)->norm1(); }
+/* norm1() before its rounding to DTYPE (per-shard partial sums are combined in double) */
+double pdwt_wavelets_norm1_f64(void* h)
+{
+    (void)W(h)->norm1();
+    return w_last_norm1_double();
+}
 void pdwt_wavelets_hard_threshold(void* h, DTYPE beta, int do_thresh_appcoeffs, int normalize) { W(h)->hard_threshold(beta, do_thresh_appcoeffs, normalize); }
 void pdwt_wavelets_group_soft_threshold(void* h, DTYPE beta, int do_thresh_appcoeffs, int normalize) { W(h)->group_soft_threshold(beta, do_thresh_appcoeffs, normalize); }
 void pdwt_wavelets_shrink(void* h, DTYPE beta, int do_thresh_appcoeffs) { W(h)->shrink(beta, do_thresh_appcoeffs); }
@@ -45,6 +53,10 @@ void pdwt_wavelets_set_state(void* h, int s) { W(h)->state = (w_state)s; }
 void pdwt_wavelets_info(void* h, w_info* out) { *out = W(h)->winfos; }
 intptr_t pdwt_wavelets_image_int_ptr(void* h) { return W(h)->image_int_ptr(); }
 intptr_t pdwt_wavelets_coeff_int_ptr(void* h, int num) { return W(h)->coeff_int_ptr(num); }
-intptr_t pdwt_wavelets_coeffs_table_ptr(void* h) { return (intptr_t)W(h)->d_coeffs; }
+intptr_t pdwt_wavelets_coeffs_table_ptr(void* h)
+{
+    (void)W(h)->coeff_int_ptr(0);  // raw band pointers leave the class: it stops tracking the coefficients' norm
+    return (intptr_t)W(h)->d_coeffs;
+}
 intptr_t pdwt_wavelets_tmp_int_ptr(void* h) { return (intptr_t)W(h)->d_tmp; }
 }

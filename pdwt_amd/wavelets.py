@@ -220,13 +220,7 @@ class Wavelets:
 
     def norm1_f64(self):
         """Sum of |c| over all bands, in double (pdwt_norm1_as_double_*): shard-combinable."""
-        out = C.c_double()
-        fn = getattr(N.hip(), "pdwt_norm1_as_double_" + ("f32" if self.dtype == np.float32 else "f64"))
-        P = C.POINTER(C.POINTER(self._ct))
-        rc = fn(C.cast(C.c_void_p(self._L.pdwt_wavelets_coeffs_table_ptr(self._h)), P), self.info, C.byref(out))
-        if rc != 0:
-            raise RuntimeError("pdwt_norm1_as_double failed: %d %s" % (rc, N.hip().pdwt_last_error_string()))
-        return out.value
+        return float(self._L.pdwt_wavelets_norm1_f64(self._h))
 
     def get_image(self):
         out = np.empty(self.shape, dtype=self.dtype)

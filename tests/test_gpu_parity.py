@@ -802,3 +802,45 @@ def test_device_buffers_of_the_caller_are_ordered_without_explicit_sync():
         ref = (base * (it + 1))
         assert float((out - ref).abs().max() / ref.abs().max()) <= 1e-5, it
         del junk
+
+
+@pytest.mark.parametrize("case", [((512, 768), "db4", 3, dict(), np.float32), ((300, 200), "db20", 2, dict(), np.float64),
+                                  ((7, 1024), "sym8", 4, dict(ndim=1), np.float32), ((128, 96), "db3", 2, dict(do_swt=1), np.float64)])
+def test_norm1_computed_inside_soft_threshold(case):
+    """soft_threshold() leaves sum|c| of the thresholded bands behind (one pass over the bands) and the norm1() that follows
+    returns it: must equal the two-pass value (an instance whose raw band pointers were handed out always takes the
+    two-pass route) and the oracle, with and without the approximation band, and every method that changes coefficients
+    must invalidate it."""
+    shape, wname, levels, kw, dt = case
+    x = np.random.RandomState(77).uniform(-1, 1, shape).astype(dt) * 20
+    tol = 2e-6 if dt == np.float32 else 1e-12
+    for app, nrm in ((0, 0), (1, 0), (1, 1)):
+        A = pdwt_amd.Wavelets(x, wname, levels, **kw)
+        B = pdwt_amd.Wavelets(x, wname, levels, **kw)
+        O = orc.OracleWavelets(x, wname, levels, **kw)
+        B.coeff_int_ptr(0)  # two-pass route from here on
+        for W in (A, B, O):
+            W.forward()
+        for k, b in enumerate(A.coeffs):
+            O.set_coeff(b, k)
+        for W in (A, B, O):
+            W.soft_threshold(1.5, app, nrm)
+        na, nb, no = A.norm1_f64(), B.norm1_f64(), O.norm1_f64()
+        assert abs(na - nb) <= 1e-12 * nb and abs(na - no) <= tol * no, (app, nrm, na, nb, no)
+        assert float(A.norm1()) == float(np.asarray(na, dtype=dt))  # the class method returns the same value rounded to DTYPE
+        for ga, gb in zip(A.coeffs, B.coeffs):
+            assert np.array_equal(ga, gb)
+        # invalidation: set_coeff, another threshold, a new forward
+        band = A.get_coeff(1) * 0 + 3
+        A.set_coeff(band, 1)
+        B.set_coeff(band, 1)
+        assert abs(A.norm1_f64() - B.norm1_f64()) <= 1e-12 * B.norm1_f64()
+        A.soft_threshold(0.5, app, nrm)
+        A.hard_threshold(1.0)
+        B.soft_threshold(0.5, app, nrm)
+        B.hard_threshold(1.0)
+        assert abs(A.norm1_f64() - B.norm1_f64()) <= 1e-12 * B.norm1_f64()
+        A.soft_threshold(0.25, app, nrm)
+        A.forward()
+        B.forward()
+        assert abs(A.norm1_f64() - B.norm1_f64()) <= 1e-12 * B.norm1_f64()
