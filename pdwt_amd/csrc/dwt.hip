@@ -29,6 +29,7 @@
 #include "dwt_stream.hpp"
 #include "dwt_casc.hpp"
 #include "casc_dev.hpp"
+#include "dwt_f64_fused.hpp"
 
 namespace pdwt {
 
@@ -555,8 +556,15 @@ static int launch_syn_cols(const T* cA, const T* cH, const T* cV, const T* cD, T
 
 // one 2D forward level: in (nr x nc) -> A,H,V,D (nr2 x nc2); t1/t2 scratch for the two-pass form
 template <typename T>
-static int level_fwd2d(const T* in, T* cA, T* cH, T* cV, T* cD, T* t1, T* t2, size_t trash_floats, int nr, int nc, int hlen, const Taps2<T>& f)
+static int level_fwd2d(const T* in, T* cA, T* cH, T* cV, T* cD, T* t1, T* t2, size_t trash_floats, int nr, int nc, int hlen, const Taps2<T>& f,
+                       T* taps_dev)
 {
+    if constexpr (sizeof(T) == 8) {  // long double-precision banks: row + column pass in one launch (dwt_f64_fused.hip)
+        if (!force_twopass()) {
+            const int rc = fwd2d_f64_fused(in, cA, cH, cV, cD, taps_dev, nr, nc, hlen, f);
+            if (rc <= 0) return rc;
+        }
+    }
     if constexpr (sizeof(T) == 4) {  // float32 fast path: LDS-free streaming kernel (dwt_stream.hip)
         if (!force_twopass()) {
             // t1 (the two-pass scratch, sized for the FULL image) is unused on this path: it serves as the trash area of
@@ -689,7 +697,8 @@ static int forward_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typ
             }
         }
         T* aout = (lev == w.nlevels - 1) ? c[0] : s.ping[pp];
-        rc = level_fwd2d(in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], s.t1, s.t2, s.trash_floats, nr, nc, w.hlen, f);
+        rc = level_fwd2d(in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], s.t1, s.t2, s.trash_floats, nr, nc, w.hlen, f,
+                         d_tmp + pdwt_tmp_elems(w) - 256);  // (the last 256 elements of d_tmp: tap scratch of the fused f64 kernels)
         if (rc != PDWT_OK) return rc;
         in = aout;
         pp ^= 1;
