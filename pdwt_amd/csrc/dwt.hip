@@ -596,8 +596,14 @@ static int level_fwd2d(const T* in, T* cA, T* cH, T* cV, T* cD, T* t1, T* t2, si
 // one 2D inverse level: bands (nri x nci) -> out (nro x nco)
 template <typename T>
 static int level_inv2d(const T* cA, const T* cH, const T* cV, const T* cD, T* out, T* t1, T* t2, int nri, int nci, int nro, int nco,
-                       int hlen, const Taps2<T>& f)
+                       int hlen, const Taps2<T>& f, T* taps_dev)
 {
+    if constexpr (sizeof(T) == 8) {  // long double-precision banks: column + row synthesis in one launch (dwt_f64_fused.hip)
+        if (!force_twopass()) {
+            const int rc = inv2d_f64_fused(cA, cH, cV, cD, out, taps_dev, nri, nci, nro, nco, hlen, f);
+            if (rc <= 0) return rc;
+        }
+    }
     if constexpr (sizeof(T) == 4) {
         if (!force_twopass()) {
             const int rc = inv2d_stream_f32(cA, cH, cV, cD, out, nri, nci, nro, nco, hlen, f);
@@ -769,7 +775,8 @@ static int inverse_separable(T* d_image, T** c, T* d_tmp, pdwt_info w, const typ
             }
         }
         T* out = (i == 0) ? d_image : s.ping[pp];
-        rc = level_inv2d(a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], out, s.t1, s.t2, tNr[i + 1], tNc[i + 1], tNr[i], tNc[i], w.hlen, f);
+        rc = level_inv2d(a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], out, s.t1, s.t2, tNr[i + 1], tNc[i + 1], tNr[i], tNc[i], w.hlen, f,
+                         d_tmp + pdwt_tmp_elems(w) - 256);
         if (rc != PDWT_OK) return rc;
         a = out;
         pp ^= 1;

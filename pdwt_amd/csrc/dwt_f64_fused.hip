@@ -237,9 +237,239 @@ int fwd2d_f64_fused(const double* in, double* cA, double* cH, double* cV, double
     return PDWT_OK;
 }
 
-int inv2d_f64_fused(const double*, const double*, const double*, const double*, double*, double*, int, int, int, int, int, const Taps2<double>&)
+// =================================================================================================
+// inverse level: column synthesis in registers (rings of H2 coefficient rows of A, H, V, D), row synthesis through LDS
+// =================================================================================================
+// Reference order (src/separable.cu:246-328): columns first -- t1 = IL_y(A) + IH_y(H), t2 = IL_y(V) + IH_y(D) -- then rows
+// out = IL_x(t1) + IH_x(t2).  SURVEY A-2 with H2 = hlen/2 taps per output, C = H2/2, SHIFT = 1 - (H2 & 1):
+//   window position p (coefficient rows p-C .. p-C+H2-1)  ->  output rows 2p-SHIFT (tap parity 1) and 2p+1-SHIFT (parity 0),
+//   the same along x: coefficient column c -> output columns 2c-SHIFT, 2c+1-SHIFT from t columns c-C .. c-C+H2-1.
+// A thread owns ONE coefficient column: rings of its A, H, V, D samples (4 x (H2-1+UNR) doubles), one new coefficient row per
+// step; the step's two rows of (t1, t2) go to LDS as 16-byte pairs, one barrier, then every thread whose whole window lies
+// inside the workgroup's 256 columns reads it (H2 aligned 16-byte reads per row) and emits its two output columns of both rows.
+// Taps per window position j: { IL[h-2-2j], IL[h-1-2j], IH[h-2-2j], IH[h-1-2j] } (parity 1 / parity 0), by scalar loads per
+// section as in the forward kernel.  Each output is (sum over the IL branch) + (sum over the IH branch), both ascending in j:
+// the order of the two-pass kernels and of the oracle.
+__global__ void k_f64_store_taps_inv(Taps2<double> f, int hlen, double* __restrict__ dst)
 {
-    return 1;  // (inverse: see below once built)
+    const int j = threadIdx.x;
+    if (j < hlen / 2) {
+        dst[4 * j + 0] = f.a[hlen - 2 - 2 * j];
+        dst[4 * j + 1] = f.a[hlen - 1 - 2 * j];
+        dst[4 * j + 2] = f.b[hlen - 2 - 2 * j];
+        dst[4 * j + 3] = f.b[hlen - 1 - 2 * j];
+    }
+}
+
+template <int HLEN, int NSEC, int UNR>
+__global__ __launch_bounds__(kTW, 2) void k_inv2d_f64fused(const double* __restrict__ cA, const double* __restrict__ cH,
+                                                            const double* __restrict__ cV, const double* __restrict__ cD,
+                                                            double* __restrict__ out, int Nri, int Nci, int NP, const double* __restrict__ taps)
+{
+    constexpr int H2 = HLEN / 2, C = H2 / 2, SHIFT = (H2 & 1) ? 0 : 1;
+    constexpr int TPS = H2 / NSEC;          // window positions per section
+    static_assert(H2 % NSEC == 0, "whole sections");
+    constexpr int TWV = kTW - (H2 - 1);     // threads of a workgroup whose window is complete = coefficient columns per tile
+    constexpr int RS = H2 - 1 + UNR;        // ring slots: slot 0 = oldest row at the start of a body, step U appends slot H2-1+U
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // [2 buffers][2 rows][kTW] of (t1, t2)
+    const int tid = threadIdx.x;
+    const int Nro = 2 * Nri, Nco = 2 * Nci;
+    const int c0 = blockIdx.x * TWV;                 // first coefficient column the tile produces outputs for
+    const int cc = c0 - C + tid;                     // this thread's coefficient column (unwrapped)
+    const int ccw = wrapi(cc, Nci);
+    // thread tid reads the window tid .. tid+H2-1 of the workgroup's t columns = coefficient columns cc .. cc+H2-1 = the window
+    // of coefficient column co = cc + C: it produces the outputs of column co
+    const int co = cc + C;
+    const bool produces = (tid < TWV) && (co < Nci);
+    const unsigned uq1 = (unsigned)wrapi(2 * co - SHIFT, Nco), uq0 = (unsigned)wrapi(2 * co + 1 - SHIFT, Nco);  // output columns
+    const int p0 = blockIdx.y * NP;                  // first window position of the chunk
+    const int np = min(NP, Nri - p0);
+    if (np <= 0) return;
+    const int nsteps = np + H2 - 1;                  // the first H2-1 steps only fill the rings
+    // uniform row offset (scalar unit) + per-lane 32-bit column offset: no 64-bit vector address arithmetic per access
+    auto grow = [&](int s) { return (size_t)wrapi(p0 - C + min(s, nsteps - 1), Nri) * Nci; };
+    const unsigned ucc = (unsigned)ccw;
+
+    double ra[RS], rh[RS], rv[RS], rd[RS];
+#pragma unroll
+    for (int k = 0; k < RS; k++) ra[k] = rh[k] = rv[k] = rd[k] = 0.0;
+    // rows 0 .. H2-2 straight into the rings
+#pragma unroll
+    for (int k = 0; k < H2 - 1; k++) {
+        const size_t o = grow(k);
+        ra[k] = (cA + o)[ucc];
+        rh[k] = (cH + o)[ucc];
+        rv[k] = (cV + o)[ucc];
+        rd[k] = (cD + o)[ucc];
+    }
+    // Memory pipeline: the UNR coefficient rows of a body are loaded straight into their ring slots at the START of the body
+    // (4 x UNR eight-byte loads per lane in flight, no staging registers): with one row of prefetch the kernel ran at the
+    // bytes-in-flight limit (2 workgroups x 8 KB per CU: 412 us at C5 level 1).
+    auto load_body = [&](int sb) {
+        static_for<UNR>([&](auto UU) {
+            constexpr int U = decltype(UU)::value;
+            const size_t o = grow(H2 - 1 + sb + U);
+            ra[H2 - 1 + U] = (cA + o)[ucc];
+            rh[H2 - 1 + U] = (cH + o)[ucc];
+            rv[H2 - 1 + U] = (cV + o)[ucc];
+            rd[H2 - 1 + U] = (cD + o)[ucc];
+        });
+    };
+
+    ctaps_t tbase = (ctaps_t)taps;
+    static_assert((UNR * 2 * NSEC) % 2 == 0, "tap buffers in phase at the end of a body");
+    double tp1l[2][TPS], tp0l[2][TPS], tp1h[2][TPS], tp0h[2][TPS];  // taps of the current / next section: IL parity 1, 0; IH parity 1, 0
+#pragma unroll
+    for (int jj = 0; jj < TPS; jj++) {
+        tp1l[0][jj] = tbase[4 * jj];
+        tp0l[0][jj] = tbase[4 * jj + 1];
+        tp1h[0][jj] = tbase[4 * jj + 2];
+        tp0h[0][jj] = tbase[4 * jj + 3];
+    }
+
+    auto step = [&](auto UU, int sb) {
+        constexpr int U = decltype(UU)::value;
+        const int s = sb + U;            // this step pushes coefficient row H2-1+s and completes window position p0+s
+        const int buf = s & 1;
+        // (the coefficient row H2-1+s of this step is already in ring slot H2-1+U: load_body)
+        // ---- column synthesis: (t1, t2) of this thread's column for the two output rows of window position p0+s ----
+        double a1, h1, v1, d1, a0, h0, v0, d0;  // parity 1 (first row) / parity 0 (second row)
+        static_for<NSEC>([&](auto SS) {
+            constexpr int sec = decltype(SS)::value;
+            constexpr int gsec = U * 2 * NSEC + sec;
+            constexpr int cur = gsec & 1, nxt = cur ^ 1;
+            constexpr int nsec = (sec + 1) % NSEC;  // (the row synthesis below starts again at section 0)
+            ctaps_t tp = tbase;
+            if constexpr (sec == 0) asm volatile("" : "+s"(tp), "+v"(ra[U]));
+            else asm volatile("" : "+s"(tp), "+v"(a1), "+v"(h1), "+v"(v1), "+v"(d1), "+v"(a0), "+v"(h0), "+v"(v0), "+v"(d0));
+#pragma unroll
+            for (int jj = 0; jj < TPS; jj++) {
+                tp1l[nxt][jj] = tp[4 * (nsec * TPS + jj)];
+                tp0l[nxt][jj] = tp[4 * (nsec * TPS + jj) + 1];
+                tp1h[nxt][jj] = tp[4 * (nsec * TPS + jj) + 2];
+                tp0h[nxt][jj] = tp[4 * (nsec * TPS + jj) + 3];
+            }
+            static_for<TPS>([&](auto JJ) {
+                constexpr int jj = decltype(JJ)::value;
+                constexpr int slot = U + sec * TPS + jj;
+                if constexpr (sec == 0 && jj == 0) {  // fma(x, t, 0) == x * t bit for bit: no zero-initialisation moves
+                    a1 = ra[slot] * tp1l[cur][jj];
+                    h1 = rh[slot] * tp1h[cur][jj];
+                    v1 = rv[slot] * tp1l[cur][jj];
+                    d1 = rd[slot] * tp1h[cur][jj];
+                    a0 = ra[slot] * tp0l[cur][jj];
+                    h0 = rh[slot] * tp0h[cur][jj];
+                    v0 = rv[slot] * tp0l[cur][jj];
+                    d0 = rd[slot] * tp0h[cur][jj];
+                } else {
+                    a1 = __builtin_fma(ra[slot], tp1l[cur][jj], a1);
+                    h1 = __builtin_fma(rh[slot], tp1h[cur][jj], h1);
+                    v1 = __builtin_fma(rv[slot], tp1l[cur][jj], v1);
+                    d1 = __builtin_fma(rd[slot], tp1h[cur][jj], d1);
+                    a0 = __builtin_fma(ra[slot], tp0l[cur][jj], a0);
+                    h0 = __builtin_fma(rh[slot], tp0h[cur][jj], h0);
+                    v0 = __builtin_fma(rv[slot], tp0l[cur][jj], v0);
+                    d0 = __builtin_fma(rd[slot], tp0h[cur][jj], d0);
+                }
+            });
+        });
+        double2* const rowsb = reinterpret_cast<double2*>(lds) + (size_t)buf * 2 * kTW;
+        rowsb[tid] = make_double2(a1 + h1, v1 + d1);        // row 2p-SHIFT
+        rowsb[kTW + tid] = make_double2(a0 + h0, v0 + d0);  // row 2p+1-SHIFT
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (LDS only: stores and prefetch loads stay in flight)
+        // ---- row synthesis: the thread's two output columns of both rows, window = t columns tid .. tid+H2-1 ----
+        double x1l[2], x1h[2], x0l[2], x0h[2];  // [row]; column parity 1 / 0; IL / IH branch
+        static_for<NSEC>([&](auto SS) {
+            constexpr int sec = decltype(SS)::value;
+            constexpr int gsec = U * 2 * NSEC + NSEC + sec;
+            constexpr int cur = gsec & 1, nxt = cur ^ 1;
+            constexpr int nsec = (sec + 1) % NSEC;
+            ctaps_t tp = tbase;
+            if constexpr (sec == 0) asm volatile("" : "+s"(tp), "+v"(a1));
+            else asm volatile("" : "+s"(tp), "+v"(x1l[0]), "+v"(x1h[0]), "+v"(x0l[0]), "+v"(x0h[0]), "+v"(x1l[1]), "+v"(x1h[1]), "+v"(x0l[1]), "+v"(x0h[1]));
+#pragma unroll
+            for (int jj = 0; jj < TPS; jj++) {
+                tp1l[nxt][jj] = tp[4 * (nsec * TPS + jj)];
+                tp0l[nxt][jj] = tp[4 * (nsec * TPS + jj) + 1];
+                tp1h[nxt][jj] = tp[4 * (nsec * TPS + jj) + 2];
+                tp0h[nxt][jj] = tp[4 * (nsec * TPS + jj) + 3];
+            }
+#pragma unroll
+            for (int jj = 0; jj < TPS; jj++) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const double2 t = rowsb[r * kTW + tid + sec * TPS + jj];  // (t1, t2) at window position sec*TPS+jj
+                    if (sec == 0 && jj == 0) {
+                        x1l[r] = t.x * tp1l[cur][jj];
+                        x1h[r] = t.y * tp1h[cur][jj];
+                        x0l[r] = t.x * tp0l[cur][jj];
+                        x0h[r] = t.y * tp0h[cur][jj];
+                    } else {
+                        x1l[r] = __builtin_fma(t.x, tp1l[cur][jj], x1l[r]);
+                        x1h[r] = __builtin_fma(t.y, tp1h[cur][jj], x1h[r]);
+                        x0l[r] = __builtin_fma(t.x, tp0l[cur][jj], x0l[r]);
+                        x0h[r] = __builtin_fma(t.y, tp0h[cur][jj], x0h[r]);
+                    }
+                }
+            }
+        });
+        if (s >= 0 && produces) {
+            // window position p = p0 + s -> output rows 2p-SHIFT, 2p+1-SHIFT; coefficient column co -> output columns 2co-SHIFT, +1
+            const int p = p0 + s;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                double* orow = out + (size_t)wrapi(2 * p - SHIFT + r, Nro) * Nco;
+                double* q1 = orow + uq1;
+                double* q0 = orow + uq0;
+                const double o1 = x1l[r] + x1h[r], o0 = x0l[r] + x0h[r];
+                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q1), "v"(o1) : "memory");
+                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q0), "v"(o0) : "memory");
+            }
+        }
+    };
+
+    // steps are numbered so that step s completes window position p0+s: the ring-filling rows were loaded above
+    for (int sb = 0; sb < np; sb += UNR) {
+        load_body(sb);
+        bool fin = false;
+        static_for<UNR>([&](auto UU) {
+            if (!fin) {
+                step(UU, sb);
+                fin = (sb + decltype(UU)::value + 1 >= np);
+            }
+        });
+#pragma unroll
+        for (int k = 0; k < H2 - 1; k++) {
+            ra[k] = ra[k + UNR];
+            rh[k] = rh[k + UNR];
+            rv[k] = rv[k + UNR];
+            rd[k] = rd[k + UNR];
+        }
+    }
+}
+
+int inv2d_f64_fused(const double* cA, const double* cH, const double* cV, const double* cD, double* out, double* taps_dev, int nri, int nci,
+                    int nro, int nco, int hlen, const Taps2<double>& f)
+{
+    if (knob(KN_F64_FUSED) != 1 || !taps_dev) return 1;
+    if (hlen != 40) return 1;
+    if (nro != 2 * nri || nco != 2 * nci || nci < kTW || nri < 4 * hlen) return 1;
+    if ((long long)nro * nco < (long long)knob(KN_F64_FUSED_MIN) * knob(KN_F64_FUSED_MIN)) return 1;
+    constexpr int H2 = 20;
+    const int twv = kTW - (H2 - 1);
+    const int tiles = idiv_up(nci, twv);
+    int chunks = std::max(1, 512 / tiles);
+    int NP = idiv_up(nri, chunks);
+    if (NP < 2 * hlen) NP = 2 * hlen;
+    chunks = idiv_up(nri, NP);
+    hipLaunchKernelGGL(k_f64_store_taps_inv, dim3(1), dim3(64), 0, stream(), f, hlen, taps_dev);
+    PDWT_CHECK_LAUNCH();
+    const size_t lds = ((size_t)2 * 2 * kTW + H2) * 2 * sizeof(double);  // (+ H2 entries: the window reads of the non-producing threads)
+    KTimer kt(K_INV2D_F64);
+    hipLaunchKernelGGL((k_inv2d_f64fused<40, 5, 4>), dim3(tiles, chunks), dim3(kTW), lds, stream(), cA, cH, cV, cD, out, nri, nci, NP,
+                       (const double*)taps_dev);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
 }
 
 }  // namespace pdwt

@@ -14,7 +14,8 @@ import sys
 
 cfg, fdir, wdir = sys.argv[1], sys.argv[2], sys.argv[3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KMAP = {"k_fwd2d_casc": "fwd2d_casc", "k_inv2d_casc": "inv2d_casc", "k_fwd2d_stream": "fwd2d_fused", "k_fwd2d_fused": "fwd2d_fused", "k_inv2d_stream": "inv2d_fused", "k_inv2d_fused": "inv2d_fused",
+KMAP = {"k_fwd2d_casc": "fwd2d_casc", "k_inv2d_casc": "inv2d_casc", "k_inv2d_cascw": "inv2d_casc", "k_fwd2d_stream": "fwd2d_stream", "k_fwd2d_fused": "fwd2d_fused", "k_inv2d_stream": "inv2d_stream", "k_inv2d_fused": "inv2d_fused",
+        "k_fwd2d_f64fused": "fwd2d_f64", "k_inv2d_f64fused": "inv2d_f64", "k_soft_thresh_sum": "thresh_sum", "k_soft_thresh": "soft_thresh", "k_abs_sum": "abs_sum",
         "k_ana_rows": "ana_rows", "k_ana_rows_tr": "ana_rows", "k_syn_rows_tr": "syn_rows", "k_ana_cols": "ana_cols", "k_syn_rows": "syn_rows", "k_syn_cols": "syn_cols",
         "k_fwd1d_stream": "ana_rows", "k_inv1d_stream": "syn_rows", "k_fwd1d_fused": "ana_rows", "k_inv1d_fused": "syn_rows", "k_inv1d_fused_pf": "syn_rows",
         "k_ana_cols_ring": "ana_cols", "k_ana_cols_ring_tr": "ana_cols", "k_syn_cols_ring": "syn_cols", "k_syn_cols_ring_tr": "syn_cols",
@@ -40,9 +41,15 @@ fetch, nf = collect(fdir, "FETCH_SIZE")
 write, _ = collect(wdir, "WRITE_SIZE")
 out_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 doc = json.load(open(out_path)) if os.path.exists(out_path) else {}
+import subprocess
+try:
+    doc["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    pass
 doc["source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 10 --warmup 3`; "
-                 "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the kernel's launches; summaries in profiles/r01v*_pmc_*.md")
-doc[cfg] = {k: {"hbm_bytes_per_launch": (2 * fetch[k] + write.get(k, 0.0)) * 1024, "fetch_kb_raw": fetch[k], "write_kb": write.get(k, 0.0), "launches_sampled": nf[k]}
+                 "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the kernel's launches; summaries in profiles/*_pmc_*.md")
+COMMIT = os.environ.get("PDWT_COMMIT", "")
+doc[cfg] = {k: {"commit": COMMIT, "hbm_bytes_per_launch": (2 * fetch[k] + write.get(k, 0.0)) * 1024, "fetch_kb_raw": fetch[k], "write_kb": write.get(k, 0.0), "launches_sampled": nf[k]}
             for k in fetch}
 json.dump(doc, open(out_path, "w"), indent=1, sort_keys=True)
 print(json.dumps(doc[cfg], indent=1))
