@@ -84,8 +84,9 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
     const float* const pH1 = b.H1 + cx1w;
     const float* const pV1 = b.V1 + cx1w;
     const float* const pD1 = b.D1 + cx1w;
-    auto off2 = [&](int s2) { return (size_t)wrapi(Q0 + s2, Nr2) * Nc2; };
-    auto off1 = [&](int r1) { return (size_t)wrapi(P0 + r1, Nr1) * Nc1; };
+    // single conditional wraps: Q0 < Nr2, P0 < Nr1 + 2C, O0 < Nr + 6C and a wave's rows are few (the host keeps chunks < Nr2/2)
+    auto off2 = [&](int s2) { return (size_t)wrap1(Q0 + s2, Nr2) * Nc2; };
+    auto off1 = [&](int r1) { return (size_t)wrap1(P0 + r1, Nr1) * Nc1; };
     const unsigned voff2 = (unsigned)cx2w * 4u, voff1 = (unsigned)cx1w * 4u, voffo = (unsigned)(valid ? cx1 : 0) * 8u;
     const lanemask_t vmask = __ballot(valid);
 
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
                 single_out(std::integral_constant<int, 3>{});
             }
         }
-        asm_store_sm(own ? out + (size_t)wrapi(O0 + g, Nr) * Nc : tr, voffo, v4f{o4[0], o4[1], o4[2], o4[3]}, vmask);
+        asm_store_sm(own ? out + (size_t)wrap1(O0 + g, Nr) * Nc : tr, voffo, v4f{o4[0], o4[1], o4[2], o4[3]}, vmask);
     };
 
     auto step = [&](auto Pp, int sb) {
