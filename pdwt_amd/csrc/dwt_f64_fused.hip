@@ -212,6 +212,13 @@ __global__ __launch_bounds__(kTW, 2) void k_fwd2d_f64fused(const double* __restr
 // =================================================================================================
 #define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
 
+int f64_store_taps_fwd(const Taps2<double>& f, int hlen, double* taps_dev)
+{
+    hipLaunchKernelGGL(k_f64_store_taps, dim3(1), dim3(64), 0, stream(), f, hlen, taps_dev);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
 int fwd2d_f64_fused(const double* in, double* cA, double* cH, double* cV, double* cD, double* taps_dev, int nr, int nc, int hlen,
                     const Taps2<double>& f)
 {
@@ -259,6 +266,13 @@ __global__ void k_f64_store_taps_inv(Taps2<double> f, int hlen, double* __restri
         dst[4 * j + 2] = f.b[hlen - 2 - 2 * j];
         dst[4 * j + 3] = f.b[hlen - 1 - 2 * j];
     }
+}
+
+int f64_store_taps_inv(const Taps2<double>& f, int hlen, double* taps_dev)
+{
+    hipLaunchKernelGGL(k_f64_store_taps_inv, dim3(1), dim3(64), 0, stream(), f, hlen, taps_dev);
+    PDWT_HIP_TRY(hipGetLastError());
+    return PDWT_OK;
 }
 
 template <int HLEN, int NSEC, int UNR>

@@ -1,0 +1,574 @@
+// dwt_f64_lds.hip -- one 2-D DWT level per launch for LONG double-precision banks (db20: 40 taps), both passes fed from LDS.
+//
+// Reference code replaced: w_kern_forward_pass1 + w_kern_forward_pass2 (src/separable.cu:91-176) of one iteration of
+// w_forward_separable (:179-209).
+//
+// Why a second fused form (dwt_f64_fused.hip keeps the column ring in REGISTERS): a 40-row ring of (lo, hi) doubles is 160 VGPRs,
+// which pins that kernel at 2 waves per SIMD with no register left to prefetch its LDS window reads -- the VALU is busy 55-62 %
+// of the time.  Here the ring lives in LDS and every thread is register-blocked over TWO outputs of the pass it runs:
+//   * a workgroup (256 threads, two per CU) owns 64 output columns and walks down a chunk, 8 input rows (4 output rows) per step;
+//   * ROW pass: thread = (input row, pair of adjacent output columns); its two 40-sample windows overlap in 38 samples, so 21
+//     aligned 16-byte LDS reads feed 160 FMAs; results (lo, hi) go to a ring of 56 rows in LDS (two planes);
+//   * COLUMN pass: thread = (plane, column, output rows q and q+2 of the step's four): 44 8-byte LDS reads feed 160 FMAs, emits
+//     (A,H) or (V,D).  The two row pairs of a step differ by two ring rows; that offset sits in the base register, so the
+//     wrap-around of the ring is the same immediate for both and rows 0, 1 are mirrored behind the last ring row;
+//   * 0.13 LDS reads per FMA as before, but ~100 VGPRs of read-ahead instead of none; the column pass of a group of rows runs in the
+//     same step as the row pass of the NEXT rows (one barrier per step), and both passes of a section share the section's taps,
+//     which arrive by scalar loads through a laundered constant-address-space pointer exactly as in dwt_f64_fused.hip.
+//   * Bank conflicts: the 16 lanes an LDS cycle serves start their windows 32 bytes apart (two output columns) -- a 2-way conflict
+//     on 16-byte reads.  A wave therefore works on TWO input rows whose LDS images are an ODD number of 16-byte slots apart
+//     (row = 83 slots), and the lanes are dealt so that every lane group holds eight windows of each row: 16 distinct slots.
+//   * The ring position of a step repeats every 7 steps; the body is unrolled over those 7 phases so that every LDS address is
+//     base register + immediate.
+// Per-sample arithmetic: taps in ascending window position, one FMA per tap, rows before columns -- the reference's and the
+// oracle's order: bit-identical to the two-pass kernels.
+#include "dwt_f64_fused.hpp"
+
+#include <algorithm>
+#include <type_traits>
+
+#include "stream_dev.hpp"
+
+namespace pdwt {
+
+namespace {
+constexpr int kNT = 256;      // threads per workgroup
+constexpr int kNCW = 64;      // output columns per workgroup
+constexpr int kNIR = 8;       // input rows per step (= 4 output rows)
+constexpr int kRing = 56;     // ring rows in LDS: window of 46 rows (two output rows + their neighbours) + the 8 rows being written
+constexpr int kPhases = 7;    // kRing / kNIR
+constexpr int kLag = 6;       // the column pass of step s emits output rows 4(s-kLag) .. +3
+typedef const double __attribute__((address_space(4))) * ctaps_t;
+typedef double dbl2 __attribute__((ext_vector_type(2)));  // a register pair the inline asm can take as ONE operand
+// The taps, in the order the kernels consume them, travel as the FIRST kernel argument: the kernarg segment is constant memory, so
+// the sections' scalar loads read it directly (no staging launch, no device scratch).
+struct TapTable {
+    double t[2 * PDWT_MAX_FILTER_WIDTH];
+};
+__device__ __forceinline__ ctaps_t kernarg_taps() { return (ctaps_t)__builtin_amdgcn_kernarg_segment_ptr(); }
+}  // namespace
+
+template <int HLEN>
+struct F64Lds {
+    static constexpr int C = HLEN / 2 - 1;
+    static constexpr int LWI = 2 * kNCW + HLEN - 2;  // input columns staged per row (doubles)
+    static constexpr int PAIRS = LWI / 2;            // 16-byte slots per staged row; must be odd (bank spreading, see above)
+    static constexpr int kColStride = (kRing + 2) * 8;          // ring planes are column-major: [column][ring row], + mirror of rows 0, 1
+    static constexpr int kPlaneBytes = kColStride * kNCW;
+    static constexpr int kInBufBytes = kNIR * LWI * 8;
+    static constexpr int kLdsBytes = 2 * kPlaneBytes + 2 * kInBufBytes;
+    static_assert(PAIRS % 2 == 1, "staged rows must be an odd number of 16-byte slots apart");
+    static_assert(HLEN % 8 == 0, "sections of 8 taps");
+    // the window of the last output row of a group ends kLag steps back
+    static_assert(2 * 3 + 2 + HLEN - 1 <= kNIR * (kLag - 1) + kNIR - 1 && kRing <= 58 && 2 * kPlaneBytes + 2 * kInBufBytes <= 81920, "column windows must be complete when their step starts");
+    static_assert(kNIR * (kLag + 1) - kRing <= 2, "the rows a step writes must not be part of the windows it reads");
+};
+
+template <int HLEN>
+__global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through kernarg_taps()*/, const double* __restrict__ in,
+                                                          double* __restrict__ cA, double* __restrict__ cH, double* __restrict__ cV,
+                                                          double* __restrict__ cD, int Nr, int Nc, int RO)
+{
+    using G = F64Lds<HLEN>;
+    constexpr int C = G::C, LWI = G::LWI, PAIRS = G::PAIRS;
+    constexpr int NSEC = HLEN / 8;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Nc2 = Nc >> 1, Nr2 = Nr >> 1;
+    const int i0 = blockIdx.x * kNCW;
+    const int y0 = blockIdx.y * RO;
+    const int nout = min(RO, Nr2 - y0);
+    if (nout <= 0) return;
+    const int ngroups = (nout + 3) >> 2;
+    const int nsteps = ngroups + kLag;
+
+    // ---- staging role: thread -> (row of the step, slots k0, k0+32, k0+64 of that row)
+    const int srow = tid >> 5, k0 = tid & 31;
+    const int cbase = 2 * i0 - C;  // LDS column j <-> input column cbase + j
+    int gc[3][2];
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        gc[m][0] = wrapi(cbase + 2 * (k0 + 32 * m), Nc);
+        gc[m][1] = wrapi(cbase + 2 * (k0 + 32 * m) + 1, Nc);
+    }
+    const bool third = k0 + 64 < PAIRS;
+    // chunk-local row rho <-> image row 2*y0 - C - 2 + rho (two leading rows align the output groups with the steps)
+    int rnext = wrapi(2 * y0 - C - 2, Nr);  // image row of rho = 8*(step to stage)
+    double st[3][2];
+    auto load_rows = [&]() {
+        int r = rnext + srow;
+        r = r >= Nr ? r - Nr : r;
+        const double* p = in + (size_t)r * Nc;
+        st[0][0] = p[gc[0][0]];
+        st[0][1] = p[gc[0][1]];
+        st[1][0] = p[gc[1][0]];
+        st[1][1] = p[gc[1][1]];
+        if (third) {
+            st[2][0] = p[gc[2][0]];
+            st[2][1] = p[gc[2][1]];
+        }
+        rnext += kNIR;
+        rnext = rnext >= Nr ? rnext - Nr : rnext;
+    };
+    char* const in_lds = lds_raw + 2 * G::kPlaneBytes;
+    int stage_off = srow * LWI * 8 + k0 * 16;  // within an input buffer
+    auto store_rows = [&](int buf) {
+        char* b = in_lds + buf * G::kInBufBytes + stage_off;
+        *reinterpret_cast<double2*>(b) = make_double2(st[0][0], st[0][1]);
+        *reinterpret_cast<double2*>(b + 512) = make_double2(st[1][0], st[1][1]);
+        if (third) *reinterpret_cast<double2*>(b + 1024) = make_double2(st[2][0], st[2][1]);
+    };
+
+    // ---- row-pass role: lane -> (row bit, column pair); every 16-lane LDS group holds 8 windows of each of the wave's two rows
+    const int rbit = (lane >> 3) & 1;
+    const int cp = (((lane >> 5) & 1) << 4) | (((lane >> 2) & 1) << 3) | (((lane >> 4) & 1) << 2) | (lane & 3);
+    const int rrow = 2 * w + rbit;
+    const int row_rd = rrow * LWI * 8 + cp * 32;             // window of output column 2cp starts at LDS column 4cp
+    const int row_wr = 2 * cp * G::kColStride + rrow * 8;     // ring row (8*phase + rrow), columns 2cp, 2cp+1 (lo plane; hi plane + kPlaneBytes)
+    // ---- column-pass role: wave -> (plane, row pair), lane -> column
+    const int plane = w & 1, rp = w >> 1;
+    const char* const col_rd = lds_raw + plane * G::kPlaneBytes + lane * G::kColStride + rp * 16;
+    double* const outL = plane ? cV : cA;
+    double* const outH = plane ? cD : cH;
+    const bool col_ok = i0 + lane < Nc2;
+
+    ctaps_t tbase = kernarg_taps();
+    double tl[2][8], th[2][8];
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) {
+        tl[0][jj] = tbase[2 * jj];
+        th[0][jj] = tbase[2 * jj + 1];
+    }
+
+    load_rows();
+    store_rows(0);
+    __syncthreads();
+
+    auto step = [&](auto PHC, int s) {
+        constexpr int PH = decltype(PHC)::value;
+        constexpr int cbase_row = kNIR * ((PH + kPhases - (kLag % kPhases)) % kPhases) + 2;  // ring row of k = 0 (rp = 0)
+        const int buf = s & 1;
+        load_rows();  // rows of step s+1, in flight while this step computes
+        const char* xr = in_lds + buf * G::kInBufBytes + row_rd;
+        double lo0 = 0.0, hi0 = 0.0, lo1 = 0.0, hi1 = 0.0;  // row pass: output columns 2cp, 2cp+1 of row rrow
+        double a0 = 0.0, h0 = 0.0, a1 = 0.0, h1 = 0.0;      // column pass: output rows 4g+rp, 4g+rp+2 of this plane
+        // P[m] = samples 2m, 2m+1 of the row window (42 samples); Q[u] = ring rows k = 2u, 2u+1 of the column window (44 rows).
+        // Section sec consumes P[4sec .. 4sec+4] and Q[4sec .. 4sec+5]; they are loaded one section AHEAD.
+        dbl2 P[21], Q[22];
+        auto ldP = [&](auto MM) {
+            constexpr int m = decltype(MM)::value;
+            P[m] = *reinterpret_cast<const dbl2*>(xr + m * 16);
+        };
+        auto ldQ = [&](auto UU) {
+            constexpr int u = decltype(UU)::value;
+            Q[u] = *reinterpret_cast<const dbl2*>(col_rd + ((cbase_row + 2 * u) % kRing) * 8);
+        };
+        static_for<5>([&](auto MM) { ldP(MM); });
+        static_for<6>([&](auto UU) { ldQ(UU); });
+        static_for<NSEC>([&](auto SS) {
+            constexpr int sec = decltype(SS)::value;
+            constexpr int gsec = PH * NSEC + sec;
+            constexpr int cur = gsec & 1, nxt = cur ^ 1;
+            constexpr int nsec = (sec + 1) % NSEC;
+            // Ordering point.  Everything this section consumes (its LDS data and its taps) passes through the statement, so the
+            // one wait it needs -- lgkmcnt(0): scalar loads return out of order -- sits HERE, before the next section's loads are
+            // issued, and nothing further has to be waited for until the next ordering point.
+            ctaps_t tp = tbase;
+            if constexpr (sec == 0) asm volatile("" : "+v"(P[0]), "+v"(Q[0]), "+v"(Q[1]));
+            asm volatile(""
+                         : "+s"(tp), "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1), "+v"(a0), "+v"(h0), "+v"(a1), "+v"(h1), "+v"(P[4 * sec + 1]),
+                           "+v"(P[4 * sec + 2]), "+v"(P[4 * sec + 3]), "+v"(P[4 * sec + 4]), "+v"(Q[4 * sec + 2]), "+v"(Q[4 * sec + 3]),
+                           "+v"(Q[4 * sec + 4]), "+v"(Q[4 * sec + 5]), "+s"(tl[cur][0]), "+s"(tl[cur][7]));
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                tl[nxt][jj] = tp[2 * (nsec * 8 + jj)];
+                th[nxt][jj] = tp[2 * (nsec * 8 + jj) + 1];
+            }
+            if constexpr (sec + 1 < NSEC) {
+                static_for<4>([&](auto MM) { ldP(std::integral_constant<int, 4 * (sec + 1) + 1 + decltype(MM)::value>{}); });
+                static_for<4>([&](auto UU) { ldQ(std::integral_constant<int, 4 * (sec + 1) + 2 + decltype(UU)::value>{}); });
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the loads above are issued BEFORE this section's arithmetic, not wherever the scheduler likes
+            // row pass: tap j meets sample j (first output) and sample j+2 (second output)
+            static_for<4>([&](auto MM) {
+                constexpr int m = decltype(MM)::value;
+                constexpr int jj = 2 * m;
+                const dbl2 p = P[4 * sec + m], q = P[4 * sec + m + 1];
+                lo0 = __builtin_fma(p.x, tl[cur][jj], lo0);
+                hi0 = __builtin_fma(p.x, th[cur][jj], hi0);
+                lo1 = __builtin_fma(q.x, tl[cur][jj], lo1);
+                hi1 = __builtin_fma(q.x, th[cur][jj], hi1);
+                lo0 = __builtin_fma(p.y, tl[cur][jj + 1], lo0);
+                hi0 = __builtin_fma(p.y, th[cur][jj + 1], hi0);
+                lo1 = __builtin_fma(q.y, tl[cur][jj + 1], lo1);
+                hi1 = __builtin_fma(q.y, th[cur][jj + 1], hi1);
+            });
+            // column pass: output rows 4g+rp and 4g+rp+2 (g = s-kLag); ring rows rho = 8g + 2 + 2rp + k, tap j meets k = j (first
+            // row) and k = j+4 (second row).  (During the first kLag steps of a chunk this works on rows that do not exist yet; nothing
+            // is stored.)
+            static_for<4>([&](auto MM) {
+                constexpr int m = decltype(MM)::value;
+                constexpr int jj = 2 * m;
+                const dbl2 p = Q[4 * sec + m], q = Q[4 * sec + m + 2];
+                a0 = __builtin_fma(p.x, tl[cur][jj], a0);
+                h0 = __builtin_fma(p.x, th[cur][jj], h0);
+                a1 = __builtin_fma(q.x, tl[cur][jj], a1);
+                h1 = __builtin_fma(q.x, th[cur][jj], h1);
+                a0 = __builtin_fma(p.y, tl[cur][jj + 1], a0);
+                h0 = __builtin_fma(p.y, th[cur][jj + 1], h0);
+                a1 = __builtin_fma(q.y, tl[cur][jj + 1], a1);
+                h1 = __builtin_fma(q.y, th[cur][jj + 1], h1);
+            });
+        });
+        // new ring rows 8*PH + rrow (ring planes are stored column-major: the column pass reads two rows per 16 bytes)
+        {
+            char* wr = lds_raw + PH * kNIR * 8 + row_wr;
+            *reinterpret_cast<double*>(wr) = lo0;
+            *reinterpret_cast<double*>(wr + G::kColStride) = lo1;
+            *reinterpret_cast<double*>(wr + G::kPlaneBytes) = hi0;
+            *reinterpret_cast<double*>(wr + G::kPlaneBytes + G::kColStride) = hi1;
+            if constexpr (PH == 0) {
+                if (w == 0) {  // ring rows 0, 1 again behind row kRing-1
+                    *reinterpret_cast<double*>(wr + kRing * 8) = lo0;
+                    *reinterpret_cast<double*>(wr + kRing * 8 + G::kColStride) = lo1;
+                    *reinterpret_cast<double*>(wr + kRing * 8 + G::kPlaneBytes) = hi0;
+                    *reinterpret_cast<double*>(wr + kRing * 8 + G::kPlaneBytes + G::kColStride) = hi1;
+                }
+            }
+        }
+        store_rows(buf ^ 1);
+        if (s >= kLag && col_ok) {
+            const int qq = 4 * (s - kLag) + rp;
+            const size_t o = (size_t)(y0 + qq) * Nc2 + i0 + lane;
+            if (qq < nout) {
+                double *pa = outL + o, *ph = outH + o;
+                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(pa), "v"(a0) : "memory");
+                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(ph), "v"(h0) : "memory");
+            }
+            if (qq + 2 < nout) {
+                double *pa = outL + o + 2 * (size_t)Nc2, *ph = outH + o + 2 * (size_t)Nc2;
+                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(pa), "v"(a1) : "memory");
+                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(ph), "v"(h1) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    for (int sb = 0; sb < nsteps; sb += kPhases) {
+        bool fin = false;
+        static_for<kPhases>([&](auto PHC) {
+            if (!fin) {
+                step(PHC, sb + decltype(PHC)::value);
+                fin = (sb + decltype(PHC)::value + 1 >= nsteps);
+            }
+        });
+        if constexpr ((kPhases * NSEC) % 2 == 1) {  // an odd number of sections per body: bring the tap buffers back in phase
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                tl[0][jj] = tl[1][jj];
+                th[0][jj] = th[1][jj];
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+#define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
+
+int fwd2d_f64_lds(const double* in, double* cA, double* cH, double* cV, double* cD, double* taps_dev, int nr, int nc, int hlen,
+                  const Taps2<double>& f)
+{
+    if (knob(KN_F64_LDS) != 1) return 1;
+    (void)taps_dev;
+    if (hlen != 40) return 1;
+    using G = F64Lds<40>;
+    if ((nr & 1) || (nc & 1) || nr < 2 * kNIR || nc < 2) return 1;
+    if ((long long)nr * nc < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
+    const int nr2 = nr / 2, nc2 = nc / 2;
+    const int strips = idiv_up(nc2, kNCW);
+    // two workgroups per CU; a chunk pays kLag steps of warm-up, so no shorter than kLag groups of rows unless the level is tiny
+    int chunks = std::max(1, knob(KN_F64_LDS_WGS) / strips);
+    int RO = idiv_up(idiv_up(nr2, chunks), 4) * 4;
+    RO = std::max(RO, 4 * knob(KN_F64_LDS_MINGROUPS));
+    chunks = idiv_up(nr2, RO);
+    static bool attr_done = false;
+    if (!attr_done) {
+        PDWT_HIP_TRY(hipFuncSetAttribute((const void*)k_fwd2d_f64lds<40>, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
+        attr_done = true;
+    }
+    TapTable tt;  // window position j meets { L[hlen-1-j], H[hlen-1-j] } (SURVEY A-1: out[i] = sum_j x[2i-c+j] F[hlen-1-j])
+    for (int j = 0; j < hlen; j++) {
+        tt.t[2 * j] = f.a[hlen - 1 - j];
+        tt.t[2 * j + 1] = f.b[hlen - 1 - j];
+    }
+    KTimer kt(K_FWD2D_F64);
+    hipLaunchKernelGGL((k_fwd2d_f64lds<40>), dim3(strips, chunks), dim3(kNT), G::kLdsBytes, stream(), tt, in, cA, cH, cV, cD, nr, nc, RO);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
+// =================================================================================================
+// inverse level
+// =================================================================================================
+// Reference code replaced: w_kern_inverse_pass1 + w_kern_inverse_pass2 (src/separable.cu:246-328) of one iteration of
+// w_inverse_separable (:332-364).  Order kept: columns first -- t1 = IL_y(A) + IH_y(H), t2 = IL_y(V) + IH_y(D) -- then rows
+// out = IL_x(t1) + IH_x(t2).  SURVEY A-2 with H2 = hlen/2 taps per output, C = H2/2, SHIFT = 1 - (H2 & 1):
+//   window position p (coefficient rows p-C .. p-C+H2-1) -> output rows 2p-SHIFT (tap parity 1) and 2p+1-SHIFT (parity 0);
+//   the same along x: coefficient column c -> output columns 2c-SHIFT, 2c+1-SHIFT from t columns c-C .. c-C+H2-1.
+//
+// dwt_f64_fused.hip keeps rings of all four bands in every lane (184 VGPRs).  Here a thread owns ONE coefficient column of ONE band
+// pair -- waves 0,1: (A, H) -> t1, waves 2,3: (V, D) -> t2 -- so its rings are half as large, and the row synthesis is register-blocked
+// over two adjacent coefficient columns (21 16-byte LDS reads of (t1, t2) pairs feed 160 FMAs; the fused kernel reads 40):
+//   * a workgroup owns 108 coefficient columns (+ H2-1 of halo = 127 threads per band pair) and walks down a chunk, two window
+//     positions (four output rows) per step;
+//   * COLUMN synthesis from the register rings (new coefficient rows are loaded straight into their ring slots, a whole body of
+//     steps ahead), results (t1 | t2) to an LDS buffer of 4 rows;
+//   * ROW synthesis of the PREVIOUS step's 4 rows in the same step (one barrier per step, the two passes share the section's taps):
+//     thread = (row, pair of coefficient columns) -> 4 output samples of that row.  Rows are an odd number of 16-byte slots apart and
+//     the lanes are dealt as in the forward kernel: no bank conflicts.
+// Every output is (sum over the IL branch) + (sum over the IH branch), both ascending in the window position: the order of the
+// two-pass kernels and of the oracle.
+namespace {
+constexpr int kINCW = 108;  // coefficient columns a workgroup produces outputs for
+constexpr int kISB = 4;     // steps per unrolled body (ring slots are compile-time constants; the ring is shifted once per body)
+}  // namespace
+
+template <int HLEN>
+struct F64Inv {
+    static constexpr int H2 = HLEN / 2, C = H2 / 2, SHIFT = (H2 & 1) ? 0 : 1;
+    static constexpr int NCOL = kINCW + H2 - 1;       // coefficient columns whose t values the workgroup needs (<= 128)
+    static constexpr int TSLOTS = 129;                // 16-byte slots per row of the t buffer (odd: bank spreading)
+    static constexpr int kTRowBytes = TSLOTS * 16;
+    static constexpr int kTBufBytes = 4 * kTRowBytes;
+    static constexpr int kLdsBytes = 2 * kTBufBytes;
+    static constexpr int RS = H2 - 1 + 2 * kISB;      // ring slots
+    static_assert(NCOL <= 128 && kINCW % 2 == 0 && H2 % 4 == 0, "geometry");
+};
+
+template <int HLEN>
+__global__ __launch_bounds__(kNT, 2) void k_inv2d_f64lds(TapTable /*read through kernarg_taps()*/, const double* __restrict__ cA,
+                                                          const double* __restrict__ cH, const double* __restrict__ cV,
+                                                          const double* __restrict__ cD, double* __restrict__ out, int Nri, int Nci, int NP)
+{
+    using G = F64Inv<HLEN>;
+    constexpr int H2 = G::H2, C = G::C, SHIFT = G::SHIFT, RS = G::RS;
+    constexpr int NSEC = H2 / 4;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Nro = 2 * Nri, Nco = 2 * Nci;
+    const int c0 = blockIdx.x * kINCW;
+    const int p0 = blockIdx.y * NP;
+    const int np = min(NP, Nri - p0);
+    if (np <= 0) return;
+    const int nsteps = (np + 1) >> 1;  // column-synthesis steps; one more step drains the row synthesis
+
+    // ---- column-synthesis role: waves 0,1 -> (A, H), waves 2,3 -> (V, D); thread -> coefficient column c0 - C + lc
+    const int pair = w >> 1;
+    const int lc = tid & 127;
+    const double* const bL = pair ? cV : cA;
+    const double* const bH = pair ? cD : cH;
+    const unsigned ucc = (unsigned)wrapi(c0 - C + lc, Nci);
+    const int t_wr = lc * 16 + pair * 8;
+    // chunk-local coefficient row k <-> band row p0 - C + k; rows past the last one the chunk needs are clamped (never consumed)
+    const int klast = 2 * nsteps - 1 + H2 - 1;
+    auto grow = [&](int k) { return (size_t)wrapi(p0 - C + min(k, klast), Nri) * Nci; };
+    double r1[RS], r2[RS];
+#pragma unroll
+    for (int k = 0; k < RS; k++) r1[k] = r2[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < H2 - 1; k++) {
+        const size_t o = grow(k);
+        r1[k] = (bL + o)[ucc];
+        r2[k] = (bH + o)[ucc];
+    }
+    auto load_body = [&](int sb) {  // the 2*kISB coefficient rows the body's steps append, straight into their ring slots
+        static_for<2 * kISB>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            const size_t o = grow(H2 - 1 + 2 * sb + k);
+            r1[H2 - 1 + k] = (bL + o)[ucc];
+            r2[H2 - 1 + k] = (bH + o)[ucc];
+        });
+    };
+
+    // ---- row-synthesis role: wave -> (position of the step, column half), lane -> (parity row, pair of coefficient columns)
+    const int rg = w >> 1, ch = w & 1;
+    const int rbit = (lane >> 3) & 1;
+    const int cp = (((lane >> 5) & 1) << 4) | (((lane >> 2) & 1) << 3) | (((lane >> 4) & 1) << 2) | (lane & 3);
+    const bool row_thread = cp < 27;
+    const int q = row_thread ? 27 * ch + cp : 0;             // column pair: coefficient columns c0 + 2q, c0 + 2q + 1
+    const int t_rd = (2 * rg + rbit) * G::kTRowBytes + q * 32;  // window of column c0+2q starts at t slot 2q
+    const int co = c0 + 2 * q;
+    unsigned uq[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) uq[k] = (unsigned)wrapi(2 * co - SHIFT + k, Nco);
+    const bool okA = row_thread && co < Nci, okB = row_thread && co + 1 < Nci;
+
+    ctaps_t tbase = kernarg_taps();
+    double tp1l[2][4], tp0l[2][4], tp1h[2][4], tp0h[2][4];  // taps of the current / next section: IL parity 1, 0; IH parity 1, 0
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+        tp1l[0][jj] = tbase[4 * jj];
+        tp0l[0][jj] = tbase[4 * jj + 1];
+        tp1h[0][jj] = tbase[4 * jj + 2];
+        tp0h[0][jj] = tbase[4 * jj + 3];
+    }
+
+    auto step = [&](auto UU, int s) {
+        constexpr int U = decltype(UU)::value;  // step within the body: window positions 2U, 2U+1 of the body = ring slots 2U+pos+j
+        const char* trow = lds_raw + ((s + 1) & 1) * G::kTBufBytes + t_rd;  // the previous step's rows
+        double cs1[2], cg1[2], cs0[2], cg0[2];  // column synthesis [position]: IL/IH branch, parity 1/0
+        double x1l[2], x1h[2], x0l[2], x0h[2];  // row synthesis [column of the pair]
+        dbl2 P[H2 + 1];                         // (t1, t2) at window slots 0 .. H2 of the pair
+        auto ldP = [&](auto MM) {
+            constexpr int m = decltype(MM)::value;
+            P[m] = *reinterpret_cast<const dbl2*>(trow + m * 16);
+        };
+        static_for<5>([&](auto MM) { ldP(MM); });
+        static_for<NSEC>([&](auto SS) {
+            constexpr int sec = decltype(SS)::value;
+            constexpr int gsec = U * NSEC + sec;
+            constexpr int cur = gsec & 1, nxt = cur ^ 1;
+            constexpr int nsec = (sec + 1) % NSEC;
+            ctaps_t tp = tbase;
+            if constexpr (sec == 0)
+                asm volatile("" : "+s"(tp), "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]), "+v"(P[4]), "+s"(tp1l[cur][0]), "+s"(tp0h[cur][3]));
+            else
+                asm volatile(""
+                             : "+s"(tp), "+v"(cs1[0]), "+v"(cg1[0]), "+v"(cs0[0]), "+v"(cg0[0]), "+v"(cs1[1]), "+v"(cg1[1]), "+v"(cs0[1]), "+v"(cg0[1]),
+                               "+v"(x1l[0]), "+v"(x1h[0]), "+v"(x0l[0]), "+v"(x0h[0]), "+v"(x1l[1]), "+v"(x1h[1]), "+v"(x0l[1]), "+v"(x0h[1]),
+                               "+v"(P[4 * sec + 1]), "+v"(P[4 * sec + 2]), "+v"(P[4 * sec + 3]), "+v"(P[4 * sec + 4]), "+s"(tp1l[cur][0]),
+                               "+s"(tp0h[cur][3]));
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                tp1l[nxt][jj] = tp[4 * (nsec * 4 + jj)];
+                tp0l[nxt][jj] = tp[4 * (nsec * 4 + jj) + 1];
+                tp1h[nxt][jj] = tp[4 * (nsec * 4 + jj) + 2];
+                tp0h[nxt][jj] = tp[4 * (nsec * 4 + jj) + 3];
+            }
+            if constexpr (sec + 1 < NSEC) {
+                static_for<4>([&](auto MM) { ldP(std::integral_constant<int, 4 * (sec + 1) + 1 + decltype(MM)::value>{}); });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<4>([&](auto JJ) {
+                constexpr int jj = decltype(JJ)::value;
+                constexpr int j = 4 * sec + jj;
+                // column synthesis of the two window positions of this step
+                static_for<2>([&](auto PP) {
+                    constexpr int pos = decltype(PP)::value;
+                    constexpr int slot = 2 * U + pos + j;
+                    if constexpr (j == 0) {  // fma(x, t, 0) == x * t: no zero-initialisation moves
+                        cs1[pos] = r1[slot] * tp1l[cur][jj];
+                        cg1[pos] = r2[slot] * tp1h[cur][jj];
+                        cs0[pos] = r1[slot] * tp0l[cur][jj];
+                        cg0[pos] = r2[slot] * tp0h[cur][jj];
+                    } else {
+                        cs1[pos] = __builtin_fma(r1[slot], tp1l[cur][jj], cs1[pos]);
+                        cg1[pos] = __builtin_fma(r2[slot], tp1h[cur][jj], cg1[pos]);
+                        cs0[pos] = __builtin_fma(r1[slot], tp0l[cur][jj], cs0[pos]);
+                        cg0[pos] = __builtin_fma(r2[slot], tp0h[cur][jj], cg0[pos]);
+                    }
+                });
+                // row synthesis of the previous step's rows: the pair's columns read window slots j and j+1
+                static_for<2>([&](auto KK) {
+                    constexpr int k = decltype(KK)::value;
+                    const dbl2 t = P[j + k];
+                    if constexpr (j == 0) {
+                        x1l[k] = t.x * tp1l[cur][jj];
+                        x1h[k] = t.y * tp1h[cur][jj];
+                        x0l[k] = t.x * tp0l[cur][jj];
+                        x0h[k] = t.y * tp0h[cur][jj];
+                    } else {
+                        x1l[k] = __builtin_fma(t.x, tp1l[cur][jj], x1l[k]);
+                        x1h[k] = __builtin_fma(t.y, tp1h[cur][jj], x1h[k]);
+                        x0l[k] = __builtin_fma(t.x, tp0l[cur][jj], x0l[k]);
+                        x0h[k] = __builtin_fma(t.y, tp0h[cur][jj], x0h[k]);
+                    }
+                });
+            });
+        });
+        // this step's four rows of t: [position 0: parity 1, parity 0][position 1: parity 1, parity 0]
+        {
+            char* tw = lds_raw + (s & 1) * G::kTBufBytes + t_wr;
+            *reinterpret_cast<double*>(tw) = cs1[0] + cg1[0];
+            *reinterpret_cast<double*>(tw + G::kTRowBytes) = cs0[0] + cg0[0];
+            *reinterpret_cast<double*>(tw + 2 * G::kTRowBytes) = cs1[1] + cg1[1];
+            *reinterpret_cast<double*>(tw + 3 * G::kTRowBytes) = cs0[1] + cg0[1];
+        }
+        // outputs of the previous step: window position p -> output rows 2p-SHIFT (+rbit); coefficient columns co, co+1 -> 4 columns
+        if (s >= 1) {
+            const int pl = 2 * (s - 1) + rg;  // chunk-local window position
+            if (pl < np) {
+                double* orow = out + (size_t)wrapi(2 * (p0 + pl) - SHIFT + rbit, Nro) * Nco;
+                if (okA) {
+                    double *q1 = orow + uq[0], *q0 = orow + uq[1];
+                    const double o1 = x1l[0] + x1h[0], o0 = x0l[0] + x0h[0];
+                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q1), "v"(o1) : "memory");
+                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q0), "v"(o0) : "memory");
+                }
+                if (okB) {
+                    double *q1 = orow + uq[2], *q0 = orow + uq[3];
+                    const double o1 = x1l[1] + x1h[1], o0 = x0l[1] + x0h[1];
+                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q1), "v"(o1) : "memory");
+                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q0), "v"(o0) : "memory");
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    for (int sb = 0; sb <= nsteps; sb += kISB) {
+        load_body(sb);
+        bool fin = false;
+        static_for<kISB>([&](auto UU) {
+            if (!fin) {
+                step(UU, sb + decltype(UU)::value);
+                fin = (sb + decltype(UU)::value + 1 > nsteps);
+            }
+        });
+#pragma unroll
+        for (int k = 0; k < H2 - 1; k++) {
+            r1[k] = r1[k + 2 * kISB];
+            r2[k] = r2[k + 2 * kISB];
+        }
+        if constexpr ((kISB * NSEC) % 2 == 1) {
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                tp1l[0][jj] = tp1l[1][jj];
+                tp0l[0][jj] = tp0l[1][jj];
+                tp1h[0][jj] = tp1h[1][jj];
+                tp0h[0][jj] = tp0h[1][jj];
+            }
+        }
+    }
+}
+
+int inv2d_f64_lds(const double* cA, const double* cH, const double* cV, const double* cD, double* out, double* taps_dev, int nri, int nci,
+                  int nro, int nco, int hlen, const Taps2<double>& f)
+{
+    if (knob(KN_F64_LDS) != 1) return 1;
+    (void)taps_dev;
+    if (hlen != 40) return 1;
+    using G = F64Inv<40>;
+    if (nro != 2 * nri || nco != 2 * nci || nri < 2 || nci < 2) return 1;
+    if ((long long)nro * nco < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
+    const int strips = idiv_up(nci, kINCW);
+    int chunks = std::max(1, knob(KN_F64_LDS_WGS) / strips);
+    int NP = idiv_up(idiv_up(nri, chunks), 2) * 2;
+    NP = std::max(NP, 2 * knob(KN_F64_LDS_MINGROUPS));
+    chunks = idiv_up(nri, NP);
+    TapTable tt;  // window position j meets { IL[h-2-2j], IL[h-1-2j], IH[h-2-2j], IH[h-1-2j] } (parity 1 / parity 0)
+    for (int j = 0; j < hlen / 2; j++) {
+        tt.t[4 * j + 0] = f.a[hlen - 2 - 2 * j];
+        tt.t[4 * j + 1] = f.a[hlen - 1 - 2 * j];
+        tt.t[4 * j + 2] = f.b[hlen - 2 - 2 * j];
+        tt.t[4 * j + 3] = f.b[hlen - 1 - 2 * j];
+    }
+    KTimer kt(K_INV2D_F64);
+    hipLaunchKernelGGL((k_inv2d_f64lds<40>), dim3(strips, chunks), dim3(kNT), G::kLdsBytes, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP);
+    PDWT_CHECK_LAUNCH();
+    return PDWT_OK;
+}
+
+}  // namespace pdwt

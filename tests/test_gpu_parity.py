@@ -768,6 +768,41 @@ def test_stress_cascade_random_shapes():
         assert band_err(res[0][1], x) <= 1e-5
 
 
+def test_f64_long_filter_level_kernels_random_shapes():
+    """dwt_f64_lds.hip (db20 / float64: both passes of a level in one launch, rings in LDS / split register rings) is the same
+    arithmetic as the two-pass kernels, bit for bit, over random even shapes (strips that do not divide the width, chunks
+    shorter than the ring warm-up, depths down to 2x-the-filter levels), and as the older fused form where that one applies;
+    one geometry is also checked against the oracle."""
+    rs = np.random.RandomState(77)
+    shapes = [(2 * rs.randint(64, 900), 2 * rs.randint(64, 900), rs.randint(1, 4)) for _ in range(14)]
+    shapes += [(4096, 4096, 6), (512, 2048, 3), (2048, 256, 2), (8192, 1024, 4)]
+    for nr, nc, lev in shapes:
+        x = rs.uniform(-10, 10, (nr, nc))
+        res = []
+        for kn in (dict(), dict(force_twopass=1), dict(f64_lds=0, f64_fused_min=0)):
+            with knobs(f64_lds_min=0, **kn):
+                W = pdwt_amd.Wavelets(x, "db20", lev)
+                W.forward()
+                c = W.coeffs
+                W.inverse()
+                res.append((c, W.get_image()))
+        for other in (1, 2):
+            for k, (a, b) in enumerate(zip(res[0][0], res[other][0])):
+                assert np.array_equal(a, b), (nr, nc, lev, "band", k, "variant", other)
+            assert np.array_equal(res[0][1], res[other][1]), (nr, nc, lev, "variant", other)
+        assert band_err(res[0][1], x) <= 1e-10
+    x = rs.randn(600, 1112)
+    with knobs(f64_lds_min=0):
+        W, O = _pair(x, "db20", 3)
+        W.forward()
+        O.forward()
+        for g, o in zip(W.coeffs, O.coeffs):
+            assert band_err(g, o) <= 1e-10
+        W.inverse()
+        O.inverse()
+        assert band_err(W.get_image(), O.get_image()) <= 1e-10
+
+
 def test_norm2sq_is_the_squared_l2_norm_in_1d():
     """the reference's 1-D norm2sq adds sum|d| of the detail bands (src/wt.cu:389); fixed here.  The knob
     norm2sq_ref1d = 1 reproduces the reference value."""
