@@ -46,6 +46,19 @@ struct TapTable {
     double t[2 * PDWT_MAX_FILTER_WIDTH];
 };
 __device__ __forceinline__ ctaps_t kernarg_taps() { return (ctaps_t)__builtin_amdgcn_kernarg_segment_ptr(); }
+// uniform base (SGPR pair) + per-lane 32-bit BYTE offset: the addressing mode that needs no 64-bit vector arithmetic per access
+__device__ __forceinline__ double ld_sv(const double* base, unsigned boff)
+{
+    typedef const char __attribute__((address_space(1))) * gbytes_t;
+    typedef const double __attribute__((address_space(1))) * gdbl_t;
+    // opaque to the optimiser: keeps hipcc from folding the per-lane offset into a loop-invariant 64-bit VGPR pointer
+    asm("" : "+s"(base));
+    return *(gdbl_t)((gbytes_t)base + boff);
+}
+__device__ __forceinline__ void st_sv(double* base, unsigned boff, double v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(boff), "v"(v), "s"(base) : "memory");
+}
 }  // namespace
 
 template <int HLEN>
@@ -85,28 +98,34 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
     // ---- staging role: thread -> (row of the step, slots k0, k0+32, k0+64 of that row)
     const int srow = tid >> 5, k0 = tid & 31;
     const int cbase = 2 * i0 - C;  // LDS column j <-> input column cbase + j
-    int gc[3][2];
+    unsigned gc[3][2];  // byte offsets within an image row
 #pragma unroll
     for (int m = 0; m < 3; m++) {
-        gc[m][0] = wrapi(cbase + 2 * (k0 + 32 * m), Nc);
-        gc[m][1] = wrapi(cbase + 2 * (k0 + 32 * m) + 1, Nc);
+        gc[m][0] = 8u * (unsigned)wrapi(cbase + 2 * (k0 + 32 * m), Nc);
+        gc[m][1] = 8u * (unsigned)wrapi(cbase + 2 * (k0 + 32 * m) + 1, Nc);
     }
+    const unsigned rowb = 8u * (unsigned)Nc * (unsigned)srow;  // the thread's row within the 8 rows of a step (when they do not wrap)
     const bool third = k0 + 64 < PAIRS;
     // chunk-local row rho <-> image row 2*y0 - C - 2 + rho (two leading rows align the output groups with the steps)
     int rnext = wrapi(2 * y0 - C - 2, Nr);  // image row of rho = 8*(step to stage)
     double st[3][2];
     auto load_rows = [&]() {
-        int r = rnext + srow;
-        r = r >= Nr ? r - Nr : r;
-        const double* p = in + (size_t)r * Nc;
-        st[0][0] = p[gc[0][0]];
-        st[0][1] = p[gc[0][1]];
-        st[1][0] = p[gc[1][0]];
-        st[1][1] = p[gc[1][1]];
-        if (third) {
-            st[2][0] = p[gc[2][0]];
-            st[2][1] = p[gc[2][1]];
+        const double* p = in + (size_t)rnext * Nc;  // uniform
+        unsigned rb = rowb;
+        if (rnext + kNIR > Nr) {  // (uniform, two steps per image) the 8 rows wrap around the bottom edge
+            const int r = rnext + srow;
+            p = in;
+            rb = 8u * (unsigned)Nc * (unsigned)(r >= Nr ? r - Nr : r);
         }
+        st[0][0] = ld_sv(p, rb + gc[0][0]);
+        st[0][1] = ld_sv(p, rb + gc[0][1]);
+        st[1][0] = ld_sv(p, rb + gc[1][0]);
+        st[1][1] = ld_sv(p, rb + gc[1][1]);
+        if (third) {
+            st[2][0] = ld_sv(p, rb + gc[2][0]);
+            st[2][1] = ld_sv(p, rb + gc[2][1]);
+        }
+        (void)rowb;
         rnext += kNIR;
         rnext = rnext >= Nr ? rnext - Nr : rnext;
     };
@@ -131,6 +150,7 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
     double* const outL = plane ? cV : cA;
     double* const outH = plane ? cD : cH;
     const bool col_ok = i0 + lane < Nc2;
+    const unsigned ocol = 8u * (unsigned)(i0 + lane);
 
     ctaps_t tbase = kernarg_taps();
     double tl[2][8], th[2][8];
@@ -150,8 +170,8 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
         const int buf = s & 1;
         load_rows();  // rows of step s+1, in flight while this step computes
         const char* xr = in_lds + buf * G::kInBufBytes + row_rd;
-        double lo0 = 0.0, hi0 = 0.0, lo1 = 0.0, hi1 = 0.0;  // row pass: output columns 2cp, 2cp+1 of row rrow
-        double a0 = 0.0, h0 = 0.0, a1 = 0.0, h1 = 0.0;      // column pass: output rows 4g+rp, 4g+rp+2 of this plane
+        double lo0, hi0, lo1, hi1;  // row pass: output columns 2cp, 2cp+1 of row rrow
+        double a0, h0, a1, h1;      // column pass: output rows 4g+rp, 4g+rp+2 of this plane
         // P[m] = samples 2m, 2m+1 of the row window (42 samples); Q[u] = ring rows k = 2u, 2u+1 of the column window (44 rows).
         // Section sec consumes P[4sec .. 4sec+4] and Q[4sec .. 4sec+5]; they are loaded one section AHEAD.
         dbl2 P[21], Q[22];
@@ -174,11 +194,15 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
             // one wait it needs -- lgkmcnt(0): scalar loads return out of order -- sits HERE, before the next section's loads are
             // issued, and nothing further has to be waited for until the next ordering point.
             ctaps_t tp = tbase;
-            if constexpr (sec == 0) asm volatile("" : "+v"(P[0]), "+v"(Q[0]), "+v"(Q[1]));
-            asm volatile(""
-                         : "+s"(tp), "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1), "+v"(a0), "+v"(h0), "+v"(a1), "+v"(h1), "+v"(P[4 * sec + 1]),
-                           "+v"(P[4 * sec + 2]), "+v"(P[4 * sec + 3]), "+v"(P[4 * sec + 4]), "+v"(Q[4 * sec + 2]), "+v"(Q[4 * sec + 3]),
-                           "+v"(Q[4 * sec + 4]), "+v"(Q[4 * sec + 5]), "+s"(tl[cur][0]), "+s"(tl[cur][7]));
+            if constexpr (sec == 0)
+                asm volatile(""
+                             : "+s"(tp), "+v"(P[0]), "+v"(Q[0]), "+v"(Q[1]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]), "+v"(P[4]), "+v"(Q[2]), "+v"(Q[3]),
+                               "+v"(Q[4]), "+v"(Q[5]), "+s"(tl[cur][0]), "+s"(tl[cur][7]));
+            else
+                asm volatile(""
+                             : "+s"(tp), "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1), "+v"(a0), "+v"(h0), "+v"(a1), "+v"(h1),
+                               "+v"(P[4 * sec + 1]), "+v"(P[4 * sec + 2]), "+v"(P[4 * sec + 3]), "+v"(P[4 * sec + 4]), "+v"(Q[4 * sec + 2]),
+                               "+v"(Q[4 * sec + 3]), "+v"(Q[4 * sec + 4]), "+v"(Q[4 * sec + 5]), "+s"(tl[cur][0]), "+s"(tl[cur][7]));
 #pragma unroll
             for (int jj = 0; jj < 8; jj++) {
                 tl[nxt][jj] = tp[2 * (nsec * 8 + jj)];
@@ -194,10 +218,17 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
                 constexpr int m = decltype(MM)::value;
                 constexpr int jj = 2 * m;
                 const dbl2 p = P[4 * sec + m], q = P[4 * sec + m + 1];
-                lo0 = __builtin_fma(p.x, tl[cur][jj], lo0);
-                hi0 = __builtin_fma(p.x, th[cur][jj], hi0);
-                lo1 = __builtin_fma(q.x, tl[cur][jj], lo1);
-                hi1 = __builtin_fma(q.x, th[cur][jj], hi1);
+                if constexpr (sec == 0 && m == 0) {  // fma(x, t, 0) == x * t: no zero-initialisation moves
+                    lo0 = p.x * tl[cur][jj];
+                    hi0 = p.x * th[cur][jj];
+                    lo1 = q.x * tl[cur][jj];
+                    hi1 = q.x * th[cur][jj];
+                } else {
+                    lo0 = __builtin_fma(p.x, tl[cur][jj], lo0);
+                    hi0 = __builtin_fma(p.x, th[cur][jj], hi0);
+                    lo1 = __builtin_fma(q.x, tl[cur][jj], lo1);
+                    hi1 = __builtin_fma(q.x, th[cur][jj], hi1);
+                }
                 lo0 = __builtin_fma(p.y, tl[cur][jj + 1], lo0);
                 hi0 = __builtin_fma(p.y, th[cur][jj + 1], hi0);
                 lo1 = __builtin_fma(q.y, tl[cur][jj + 1], lo1);
@@ -210,10 +241,17 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
                 constexpr int m = decltype(MM)::value;
                 constexpr int jj = 2 * m;
                 const dbl2 p = Q[4 * sec + m], q = Q[4 * sec + m + 2];
-                a0 = __builtin_fma(p.x, tl[cur][jj], a0);
-                h0 = __builtin_fma(p.x, th[cur][jj], h0);
-                a1 = __builtin_fma(q.x, tl[cur][jj], a1);
-                h1 = __builtin_fma(q.x, th[cur][jj], h1);
+                if constexpr (sec == 0 && m == 0) {
+                    a0 = p.x * tl[cur][jj];
+                    h0 = p.x * th[cur][jj];
+                    a1 = q.x * tl[cur][jj];
+                    h1 = q.x * th[cur][jj];
+                } else {
+                    a0 = __builtin_fma(p.x, tl[cur][jj], a0);
+                    h0 = __builtin_fma(p.x, th[cur][jj], h0);
+                    a1 = __builtin_fma(q.x, tl[cur][jj], a1);
+                    h1 = __builtin_fma(q.x, th[cur][jj], h1);
+                }
                 a0 = __builtin_fma(p.y, tl[cur][jj + 1], a0);
                 h0 = __builtin_fma(p.y, th[cur][jj + 1], h0);
                 a1 = __builtin_fma(q.y, tl[cur][jj + 1], a1);
@@ -239,16 +277,14 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
         store_rows(buf ^ 1);
         if (s >= kLag && col_ok) {
             const int qq = 4 * (s - kLag) + rp;
-            const size_t o = (size_t)(y0 + qq) * Nc2 + i0 + lane;
+            const size_t o = (size_t)(y0 + qq) * Nc2;  // uniform
             if (qq < nout) {
-                double *pa = outL + o, *ph = outH + o;
-                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(pa), "v"(a0) : "memory");
-                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(ph), "v"(h0) : "memory");
+                st_sv(outL + o, ocol, a0);
+                st_sv(outH + o, ocol, h0);
             }
             if (qq + 2 < nout) {
-                double *pa = outL + o + 2 * (size_t)Nc2, *ph = outH + o + 2 * (size_t)Nc2;
-                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(pa), "v"(a1) : "memory");
-                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(ph), "v"(h1) : "memory");
+                st_sv(outL + o + 2 * (size_t)Nc2, ocol, a1);
+                st_sv(outH + o + 2 * (size_t)Nc2, ocol, h1);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -288,8 +324,9 @@ int fwd2d_f64_lds(const double* in, double* cA, double* cH, double* cV, double* 
     if ((long long)nr * nc < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
     const int nr2 = nr / 2, nc2 = nc / 2;
     const int strips = idiv_up(nc2, kNCW);
-    // two workgroups per CU; a chunk pays kLag steps of warm-up, so no shorter than kLag groups of rows unless the level is tiny
-    int chunks = std::max(1, knob(KN_F64_LDS_WGS) / strips);
+    // two workgroups per CU when the level is large; one (steps run ~1.7x faster alone) when a chunk is mostly warm-up anyway
+    const int target = (long long)nr * nc >= 2048LL * 2048 ? knob(KN_F64_LDS_WGS) : knob(KN_F64_LDS_WGS) / 2;
+    int chunks = std::max(1, target / strips);
     int RO = idiv_up(idiv_up(nr2, chunks), 4) * 4;
     RO = std::max(RO, 4 * knob(KN_F64_LDS_MINGROUPS));
     chunks = idiv_up(nr2, RO);
@@ -369,7 +406,7 @@ __global__ __launch_bounds__(kNT, 2) void k_inv2d_f64lds(TapTable /*read through
     const int lc = tid & 127;
     const double* const bL = pair ? cV : cA;
     const double* const bH = pair ? cD : cH;
-    const unsigned ucc = (unsigned)wrapi(c0 - C + lc, Nci);
+    const unsigned ucc = 8u * (unsigned)wrapi(c0 - C + lc, Nci);  // byte offset within a band row
     const int t_wr = lc * 16 + pair * 8;
     // chunk-local coefficient row k <-> band row p0 - C + k; rows past the last one the chunk needs are clamped (never consumed)
     const int klast = 2 * nsteps - 1 + H2 - 1;
@@ -380,15 +417,15 @@ __global__ __launch_bounds__(kNT, 2) void k_inv2d_f64lds(TapTable /*read through
 #pragma unroll
     for (int k = 0; k < H2 - 1; k++) {
         const size_t o = grow(k);
-        r1[k] = (bL + o)[ucc];
-        r2[k] = (bH + o)[ucc];
+        r1[k] = ld_sv(bL + o, ucc);
+        r2[k] = ld_sv(bH + o, ucc);
     }
     auto load_body = [&](int sb) {  // the 2*kISB coefficient rows the body's steps append, straight into their ring slots
         static_for<2 * kISB>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
             const size_t o = grow(H2 - 1 + 2 * sb + k);
-            r1[H2 - 1 + k] = (bL + o)[ucc];
-            r2[H2 - 1 + k] = (bH + o)[ucc];
+            r1[H2 - 1 + k] = ld_sv(bL + o, ucc);
+            r2[H2 - 1 + k] = ld_sv(bH + o, ucc);
         });
     };
 
@@ -402,7 +439,10 @@ __global__ __launch_bounds__(kNT, 2) void k_inv2d_f64lds(TapTable /*read through
     const int co = c0 + 2 * q;
     unsigned uq[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) uq[k] = (unsigned)wrapi(2 * co - SHIFT + k, Nco);
+    for (int k = 0; k < 4; k++) uq[k] = 8u * (unsigned)wrapi(2 * co - SHIFT + k, Nco);  // byte offsets within an output row
+    unsigned uqr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) uqr[k] = uq[k] + (rbit ? 8u * (unsigned)Nco : 0u);
     const bool okA = row_thread && co < Nci, okB = row_thread && co + 1 < Nci;
 
     ctaps_t tbase = kernarg_taps();
@@ -500,18 +540,33 @@ __global__ __launch_bounds__(kNT, 2) void k_inv2d_f64lds(TapTable /*read through
         if (s >= 1) {
             const int pl = 2 * (s - 1) + rg;  // chunk-local window position
             if (pl < np) {
-                double* orow = out + (size_t)wrapi(2 * (p0 + pl) - SHIFT + rbit, Nro) * Nco;
-                if (okA) {
-                    double *q1 = orow + uq[0], *q0 = orow + uq[1];
-                    const double o1 = x1l[0] + x1h[0], o0 = x0l[0] + x0h[0];
-                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q1), "v"(o1) : "memory");
-                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q0), "v"(o0) : "memory");
-                }
-                if (okB) {
-                    double *q1 = orow + uq[2], *q0 = orow + uq[3];
-                    const double o1 = x1l[1] + x1h[1], o0 = x0l[1] + x0h[1];
-                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q1), "v"(o1) : "memory");
-                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q0), "v"(o0) : "memory");
+                const int row0 = wrapi(2 * (p0 + pl) - SHIFT, Nro);  // parity-1 row; the parity-0 row is the next one (periodic)
+                const double o1a = x1l[0] + x1h[0], o0a = x0l[0] + x0h[0], o1b = x1l[1] + x1h[1], o0b = x0l[1] + x0h[1];
+                if (row0 + 1 < Nro) {  // uniform base + per-lane offset (the lane's row is part of the offset)
+                    double* orow = out + (size_t)row0 * Nco;
+                    if (okA) {
+                        st_sv(orow, uqr[0], o1a);
+                        st_sv(orow, uqr[1], o0a);
+                    }
+                    if (okB) {
+                        st_sv(orow, uqr[2], o1b);
+                        st_sv(orow, uqr[3], o0b);
+                    }
+                } else {  // rows Nro-1 and 0
+                    double* orow = out + (rbit ? (size_t)0 : (size_t)row0 * Nco);
+                    double* q;
+                    if (okA) {
+                        q = orow + (uq[0] >> 3);
+                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q), "v"(o1a) : "memory");
+                        q = orow + (uq[1] >> 3);
+                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q), "v"(o0a) : "memory");
+                    }
+                    if (okB) {
+                        q = orow + (uq[2] >> 3);
+                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q), "v"(o1b) : "memory");
+                        q = orow + (uq[3] >> 3);
+                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q), "v"(o0b) : "memory");
+                    }
                 }
             }
         }
@@ -554,7 +609,8 @@ int inv2d_f64_lds(const double* cA, const double* cH, const double* cV, const do
     if (nro != 2 * nri || nco != 2 * nci || nri < 2 || nci < 2) return 1;
     if ((long long)nro * nco < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
     const int strips = idiv_up(nci, kINCW);
-    int chunks = std::max(1, knob(KN_F64_LDS_WGS) / strips);
+    const int target = (long long)nro * nco >= 2048LL * 2048 ? knob(KN_F64_LDS_WGS) : knob(KN_F64_LDS_WGS) / 2;
+    int chunks = std::max(1, target / strips);
     int NP = idiv_up(idiv_up(nri, chunks), 2) * 2;
     NP = std::max(NP, 2 * knob(KN_F64_LDS_MINGROUPS));
     chunks = idiv_up(nri, NP);
