@@ -368,29 +368,34 @@ int fwd2d_f64_lds(const double* in, double* cA, double* cH, double* cV, double* 
 // Every output is (sum over the IL branch) + (sum over the IH branch), both ascending in the window position: the order of the
 // two-pass kernels and of the oracle.
 namespace {
-constexpr int kINCW = 108;  // coefficient columns a workgroup produces outputs for
 constexpr int kISB = 4;     // steps per unrolled body (ring slots are compile-time constants; the ring is shifted once per body)
 }  // namespace
 
-template <int HLEN>
+// NT threads per workgroup: NT/2 per band pair = coefficient columns whose t values the workgroup computes; H2-1 of them are halo.
+// NT = 256: 108 columns produced (17.6 % of the column synthesis is halo), two workgroups per CU; NT = 512: 236 columns (8 %), one.
+template <int HLEN, int NT>
 struct F64Inv {
     static constexpr int H2 = HLEN / 2, C = H2 / 2, SHIFT = (H2 & 1) ? 0 : 1;
-    static constexpr int NCOL = kINCW + H2 - 1;       // coefficient columns whose t values the workgroup needs (<= 128)
-    static constexpr int TSLOTS = 129;                // 16-byte slots per row of the t buffer (odd: bank spreading)
+    static constexpr int NCOL = NT / 2;
+    static constexpr int INCW = (NCOL - (H2 - 1)) & ~1;  // coefficient columns a workgroup produces outputs for
+    static constexpr int NPAIR = INCW / 2;
+    static constexpr int WPP = NT / 128;                 // waves per window position in the row synthesis
+    static constexpr int PPW = (NPAIR + WPP - 1) / WPP;  // column pairs per wave (<= 32)
+    static constexpr int TSLOTS = NCOL + 1;              // 16-byte slots per row of the t buffer (odd: bank spreading)
     static constexpr int kTRowBytes = TSLOTS * 16;
     static constexpr int kTBufBytes = 4 * kTRowBytes;
     static constexpr int kLdsBytes = 2 * kTBufBytes;
-    static constexpr int RS = H2 - 1 + 2 * kISB;      // ring slots
-    static_assert(NCOL <= 128 && kINCW % 2 == 0 && H2 % 4 == 0, "geometry");
+    static constexpr int RS = H2 - 1 + 2 * kISB;         // ring slots
+    static_assert(PPW <= 32 && H2 % 4 == 0 && TSLOTS % 2 == 1, "geometry");
 };
 
-template <int HLEN>
-__global__ __launch_bounds__(kNT, 2) void k_inv2d_f64lds(TapTable /*read through kernarg_taps()*/, const double* __restrict__ cA,
+template <int HLEN, int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable /*read through kernarg_taps()*/, const double* __restrict__ cA,
                                                           const double* __restrict__ cH, const double* __restrict__ cV,
                                                           const double* __restrict__ cD, double* __restrict__ out, int Nri, int Nci, int NP)
 {
-    using G = F64Inv<HLEN>;
-    constexpr int H2 = G::H2, C = G::C, SHIFT = G::SHIFT, RS = G::RS;
+    using G = F64Inv<HLEN, NT>;
+    constexpr int H2 = G::H2, C = G::C, SHIFT = G::SHIFT, RS = G::RS, kINCW = G::INCW;
     constexpr int NSEC = H2 / 4;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -402,8 +407,8 @@ __global__ __launch_bounds__(kNT, 2) void k_inv2d_f64lds(TapTable /*read through
     const int nsteps = (np + 1) >> 1;  // column-synthesis steps; one more step drains the row synthesis
 
     // ---- column-synthesis role: waves 0,1 -> (A, H), waves 2,3 -> (V, D); thread -> coefficient column c0 - C + lc
-    const int pair = w >> 1;
-    const int lc = tid & 127;
+    const int pair = w / (NT / 128);
+    const int lc = tid & (NT / 2 - 1);
     const double* const bL = pair ? cV : cA;
     const double* const bH = pair ? cD : cH;
     const unsigned ucc = 8u * (unsigned)wrapi(c0 - C + lc, Nci);  // byte offset within a band row
@@ -430,11 +435,11 @@ __global__ __launch_bounds__(kNT, 2) void k_inv2d_f64lds(TapTable /*read through
     };
 
     // ---- row-synthesis role: wave -> (position of the step, column half), lane -> (parity row, pair of coefficient columns)
-    const int rg = w >> 1, ch = w & 1;
+    const int rg = w / G::WPP, ch = w % G::WPP;
     const int rbit = (lane >> 3) & 1;
     const int cp = (((lane >> 5) & 1) << 4) | (((lane >> 2) & 1) << 3) | (((lane >> 4) & 1) << 2) | (lane & 3);
-    const bool row_thread = cp < 27;
-    const int q = row_thread ? 27 * ch + cp : 0;             // column pair: coefficient columns c0 + 2q, c0 + 2q + 1
+    const bool row_thread = cp < G::PPW && G::PPW * ch + cp < G::NPAIR;
+    const int q = row_thread ? G::PPW * ch + cp : 0;         // column pair: coefficient columns c0 + 2q, c0 + 2q + 1
     const int t_rd = (2 * rg + rbit) * G::kTRowBytes + q * 32;  // window of column c0+2q starts at t slot 2q
     const int co = c0 + 2 * q;
     unsigned uq[4];
@@ -605,11 +610,13 @@ int inv2d_f64_lds(const double* cA, const double* cH, const double* cV, const do
     if (knob(KN_F64_LDS) != 1) return 1;
     (void)taps_dev;
     if (hlen != 40) return 1;
-    using G = F64Inv<40>;
     if (nro != 2 * nri || nco != 2 * nci || nri < 2 || nci < 2) return 1;
     if ((long long)nro * nco < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
-    const int strips = idiv_up(nci, kINCW);
-    const int target = (long long)nro * nco >= 2048LL * 2048 ? knob(KN_F64_LDS_WGS) : knob(KN_F64_LDS_WGS) / 2;
+    const bool big = (long long)nro * nco >= 2048LL * 2048;
+    const bool wide = big && knob(KN_F64_LDS_INV512) == 1;  // 512-thread workgroups: less halo, one workgroup per CU
+    const int incw = wide ? F64Inv<40, 512>::INCW : F64Inv<40, 256>::INCW;
+    const int strips = idiv_up(nci, incw);
+    const int target = wide ? knob(KN_F64_LDS_WGS) / 2 : (big ? knob(KN_F64_LDS_WGS) : knob(KN_F64_LDS_WGS) / 2);
     int chunks = std::max(1, target / strips);
     int NP = idiv_up(idiv_up(nri, chunks), 2) * 2;
     NP = std::max(NP, 2 * knob(KN_F64_LDS_MINGROUPS));
@@ -622,7 +629,11 @@ int inv2d_f64_lds(const double* cA, const double* cH, const double* cV, const do
         tt.t[4 * j + 3] = f.b[hlen - 1 - 2 * j];
     }
     KTimer kt(K_INV2D_F64);
-    hipLaunchKernelGGL((k_inv2d_f64lds<40>), dim3(strips, chunks), dim3(kNT), G::kLdsBytes, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP);
+    constexpr size_t lds512 = F64Inv<40, 512>::kLdsBytes, lds256 = F64Inv<40, 256>::kLdsBytes;
+    if (wide)
+        hipLaunchKernelGGL((k_inv2d_f64lds<40, 512>), dim3(strips, chunks), dim3(512), lds512, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP);
+    else
+        hipLaunchKernelGGL((k_inv2d_f64lds<40, 256>), dim3(strips, chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
