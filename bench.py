@@ -251,6 +251,7 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
     barrier()
     sync()
     e0, e1 = L.pdwt_event_create(), L.pdwt_event_create()
+    wall0 = time.time()
     t0 = time.perf_counter()
     L.pdwt_event_record(e0)
     for _ in range(steps):
@@ -259,7 +260,9 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
     sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    wall1 = time.time()
     gpu_ms = L.pdwt_event_elapsed_ms(e0, e1)
+    power = _SAMPLER.window(wall0, wall1) if _SAMPLER is not None else None
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -380,8 +383,96 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
     del W
     return {"value": round(value, 1), "unit": cfg["unit"], "ms_per_step": round(ms_per_step, 5), "gpu_ms_per_step": round(gpu_ms / steps, 5),
             "steps": steps, "warmup": warmup, "levels": levels_eff, "workload": cfg["desc"], "dtype": "f32" if cfg["dtype"] == "float32" else "f64",
-            "sanity": sanity, "roundtrip_max_rel_err": rt_err, "roofline": roofline, "cpu_baseline": cpu,
+            "sanity": sanity, "roundtrip_max_rel_err": rt_err, "roofline": roofline, "cpu_baseline": cpu, "power": power,
             "kernels": {k: {a: round(b, 3) for a, b in v.items()} for k, v in kernels.items()}}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Shader clock and socket power during the timed region ("report sclk and power next to the number").  A helper
+# PROCESS polls amdsmi's gpu_metrics every ~2 ms into a file (a thread of this process would compete with the launch loop for
+# the interpreter lock); run_config() keeps the samples whose timestamps fall inside its timed region.  None when amdsmi is
+# not importable on the host.
+# ---------------------------------------------------------------------------------------------------------------------
+_SAMPLER_SRC = r"""
+import sys, time
+path, idx = sys.argv[1], int(sys.argv[2])
+out = open(path, "w", buffering=1)
+try:
+    import amdsmi
+    amdsmi.amdsmi_init()
+    h = amdsmi.amdsmi_get_processor_handles()[idx]
+    lim = amdsmi.amdsmi_get_power_info(h).get("power_limit")
+    out.write("# limit %s\n" % lim)
+except Exception as e:
+    out.write("# error %r\n" % (e,))
+    sys.exit(0)
+while True:
+    try:
+        m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+        ck = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 60000]
+        clk = sum(ck) / len(ck) if ck else m.get("current_gfxclk")
+        out.write("%.6f %s %s %s\n" % (time.time(), clk, m.get("current_socket_power"), m.get("temperature_hotspot")))
+    except Exception as e:
+        out.write("# error %r\n" % (e,))
+    time.sleep(0.002)
+"""
+
+
+class PowerSampler:
+    def __init__(self, device_index):
+        import subprocess, tempfile
+        self.path, self.proc = None, None
+        try:
+            fd, self.path = tempfile.mkstemp(prefix="pdwt_smi_", suffix=".txt")
+            os.close(fd)
+            self.proc = subprocess.Popen([sys.executable, "-c", _SAMPLER_SRC, self.path, str(device_index)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except Exception:
+            self.proc = None
+
+    def window(self, t0, t1):
+        """Samples with t0 <= timestamp <= t1 -> summary dict (None when there are none)."""
+        if not self.proc or not self.path:
+            return None
+        clk, pw, temp, limit = [], [], [], None
+        try:
+            for ln in open(self.path):
+                if ln.startswith("# limit"):
+                    try:
+                        limit = float(ln.split()[2]) / 1e6  # microwatts
+                    except Exception:
+                        pass
+                    continue
+                if ln.startswith("#"):
+                    continue
+                f = ln.split()
+                if len(f) < 3 or not (t0 <= float(f[0]) <= t1):
+                    continue
+                try:
+                    clk.append(float(f[1])); pw.append(float(f[2]))
+                    temp.append(float(f[3]))
+                except Exception:
+                    pass
+        except Exception:
+            return None
+        if not clk:
+            return None
+        return {"sclk_mhz": {"mean": round(sum(clk) / len(clk), 0), "min": min(clk), "max": max(clk)},
+                "socket_w": {"mean": round(sum(pw) / len(pw), 0), "max": max(pw)}, "power_limit_w": limit,
+                "hotspot_c_max": max(temp) if temp else None, "samples": len(clk),
+                "source": "amdsmi gpu_metrics (mean of the per-XCD gfx clocks, socket power), polled every ~2 ms by a helper process during the timed region"}
+
+    def close(self):
+        try:
+            if self.proc:
+                self.proc.kill()
+                self.proc.wait(timeout=5)
+            if self.path and os.path.exists(self.path):
+                os.unlink(self.path)
+        except Exception:
+            pass
+
+
+_SAMPLER = None
 
 
 _PDWT = None
@@ -431,6 +522,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    global _SAMPLER
+    if rank == 0:
+        _SAMPLER = PowerSampler(local_rank)
+        time.sleep(0.5)  # (the helper imports amdsmi)
     cfg = CONFIGS[args.config]
     res = run_config(args.config, args, L, torch, dist, rank, world, args.steps, args.warmup, args.settle_ms, args.cpu_seconds, not args.no_roofline)
 
@@ -454,10 +549,12 @@ def main():
             "dtype": res["dtype"], "data": "synthetic",
             "config": {"workload": cfg["desc"], "images_per_gpu_per_step": 1, "levels": res["levels"], "parallelism": "batch-split x%d (no data-path collective)" % world},
             "gpu_ms_per_step": res["gpu_ms_per_step"], "settle_ms": args.settle_ms, "roundtrip_max_rel_err": res["roundtrip_max_rel_err"],
-            "sanity": res["sanity"], "roofline": res["roofline"], "cpu_baseline": res["cpu_baseline"], "kernels": res["kernels"],
-            "other_configs": others,
+            "sanity": res["sanity"], "roofline": res["roofline"], "cpu_baseline": res["cpu_baseline"], "power": res["power"],
+            "kernels": res["kernels"], "other_configs": others,
         }
         print(json.dumps(line), flush=True)
+    if _SAMPLER is not None:
+        _SAMPLER.close()
     if world > 1:
         dist.destroy_process_group()
 
