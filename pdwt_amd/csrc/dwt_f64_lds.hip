@@ -110,22 +110,28 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
     int rnext = wrapi(2 * y0 - C - 2, Nr);  // image row of rho = 8*(step to stage)
     double st[3][2];
     auto load_rows = [&]() {
-        const double* p = in + (size_t)rnext * Nc;  // uniform
-        unsigned rb = rowb;
-        if (rnext + kNIR > Nr) {  // (uniform, two steps per image) the 8 rows wrap around the bottom edge
+        if (rnext + kNIR <= Nr) {  // the step's 8 rows are consecutive: uniform base + 32-bit per-lane offset
+            const double* p = in + (size_t)rnext * Nc;
+            st[0][0] = ld_sv(p, rowb + gc[0][0]);
+            st[0][1] = ld_sv(p, rowb + gc[0][1]);
+            st[1][0] = ld_sv(p, rowb + gc[1][0]);
+            st[1][1] = ld_sv(p, rowb + gc[1][1]);
+            if (third) {
+                st[2][0] = ld_sv(p, rowb + gc[2][0]);
+                st[2][1] = ld_sv(p, rowb + gc[2][1]);
+            }
+        } else {  // (uniform; at most two steps of a chunk) they wrap around the bottom edge: per-lane 64-bit row pointers
             const int r = rnext + srow;
-            p = in;
-            rb = 8u * (unsigned)Nc * (unsigned)(r >= Nr ? r - Nr : r);
+            const char* p = reinterpret_cast<const char*>(in + (size_t)(r >= Nr ? r - Nr : r) * Nc);
+            st[0][0] = *reinterpret_cast<const double*>(p + gc[0][0]);
+            st[0][1] = *reinterpret_cast<const double*>(p + gc[0][1]);
+            st[1][0] = *reinterpret_cast<const double*>(p + gc[1][0]);
+            st[1][1] = *reinterpret_cast<const double*>(p + gc[1][1]);
+            if (third) {
+                st[2][0] = *reinterpret_cast<const double*>(p + gc[2][0]);
+                st[2][1] = *reinterpret_cast<const double*>(p + gc[2][1]);
+            }
         }
-        st[0][0] = ld_sv(p, rb + gc[0][0]);
-        st[0][1] = ld_sv(p, rb + gc[0][1]);
-        st[1][0] = ld_sv(p, rb + gc[1][0]);
-        st[1][1] = ld_sv(p, rb + gc[1][1]);
-        if (third) {
-            st[2][0] = ld_sv(p, rb + gc[2][0]);
-            st[2][1] = ld_sv(p, rb + gc[2][1]);
-        }
-        (void)rowb;
         rnext += kNIR;
         rnext = rnext >= Nr ? rnext - Nr : rnext;
     };
