@@ -55,6 +55,17 @@ __device__ __forceinline__ double ld_sv(const double* base, unsigned boff)
     asm("" : "+s"(base));
     return *(gdbl_t)((gbytes_t)base + boff);
 }
+// Workgroup id -> (strip, chunk), XCD-aware.  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs; every
+// XCD is given a CONTIGUOUS run of the strip-major tile order instead, so that horizontally adjacent strips -- whose input windows
+// overlap by hlen-2 columns -- run on the same XCD at the same time and the overlap is served by that XCD's L2.
+__device__ __forceinline__ void xcd_tile(int strips, int& strip, int& chunk)
+{
+    const int T = gridDim.x, w = blockIdx.x;
+    const int x = w & 7, per = T >> 3, rem = T & 7;
+    const int L = x * per + min(x, rem) + (w >> 3);
+    strip = L % strips;
+    chunk = L / strips;
+}
 __device__ __forceinline__ void st_sv(double* base, unsigned boff, double v)
 {
     asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(boff), "v"(v), "s"(base) : "memory");
@@ -80,7 +91,7 @@ struct F64Lds {
 template <int HLEN>
 __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through kernarg_taps()*/, const double* __restrict__ in,
                                                           double* __restrict__ cA, double* __restrict__ cH, double* __restrict__ cV,
-                                                          double* __restrict__ cD, int Nr, int Nc, int RO)
+                                                          double* __restrict__ cD, int Nr, int Nc, int RO, int strips)
 {
     using G = F64Lds<HLEN>;
     constexpr int C = G::C, LWI = G::LWI, PAIRS = G::PAIRS;
@@ -88,8 +99,10 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Nc2 = Nc >> 1, Nr2 = Nr >> 1;
-    const int i0 = blockIdx.x * kNCW;
-    const int y0 = blockIdx.y * RO;
+    int strip, chunk;
+    xcd_tile(strips, strip, chunk);
+    const int i0 = strip * kNCW;
+    const int y0 = chunk * RO;
     const int nout = min(RO, Nr2 - y0);
     if (nout <= 0) return;
     const int ngroups = (nout + 3) >> 2;
@@ -347,7 +360,7 @@ int fwd2d_f64_lds(const double* in, double* cA, double* cH, double* cV, double* 
         tt.t[2 * j + 1] = f.b[hlen - 1 - j];
     }
     KTimer kt(K_FWD2D_F64);
-    hipLaunchKernelGGL((k_fwd2d_f64lds<40>), dim3(strips, chunks), dim3(kNT), G::kLdsBytes, stream(), tt, in, cA, cH, cV, cD, nr, nc, RO);
+    hipLaunchKernelGGL((k_fwd2d_f64lds<40>), dim3(strips * chunks), dim3(kNT), G::kLdsBytes, stream(), tt, in, cA, cH, cV, cD, nr, nc, RO, strips);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -398,7 +411,7 @@ struct F64Inv {
 template <int HLEN, int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable /*read through kernarg_taps()*/, const double* __restrict__ cA,
                                                           const double* __restrict__ cH, const double* __restrict__ cV,
-                                                          const double* __restrict__ cD, double* __restrict__ out, int Nri, int Nci, int NP)
+                                                          const double* __restrict__ cD, double* __restrict__ out, int Nri, int Nci, int NP, int strips)
 {
     using G = F64Inv<HLEN, NT>;
     constexpr int H2 = G::H2, C = G::C, SHIFT = G::SHIFT, RS = G::RS, kINCW = G::INCW;
@@ -406,8 +419,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Nro = 2 * Nri, Nco = 2 * Nci;
-    const int c0 = blockIdx.x * kINCW;
-    const int p0 = blockIdx.y * NP;
+    int strip, chunk;
+    xcd_tile(strips, strip, chunk);
+    const int c0 = strip * kINCW;
+    const int p0 = chunk * NP;
     const int np = min(NP, Nri - p0);
     if (np <= 0) return;
     const int nsteps = (np + 1) >> 1;  // column-synthesis steps; one more step drains the row synthesis
@@ -637,9 +652,9 @@ int inv2d_f64_lds(const double* cA, const double* cH, const double* cV, const do
     KTimer kt(K_INV2D_F64);
     constexpr size_t lds512 = F64Inv<40, 512>::kLdsBytes, lds256 = F64Inv<40, 256>::kLdsBytes;
     if (wide)
-        hipLaunchKernelGGL((k_inv2d_f64lds<40, 512>), dim3(strips, chunks), dim3(512), lds512, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP);
+        hipLaunchKernelGGL((k_inv2d_f64lds<40, 512>), dim3(strips * chunks), dim3(512), lds512, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP, strips);
     else
-        hipLaunchKernelGGL((k_inv2d_f64lds<40, 256>), dim3(strips, chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP);
+        hipLaunchKernelGGL((k_inv2d_f64lds<40, 256>), dim3(strips * chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP, strips);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
