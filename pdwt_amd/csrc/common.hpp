@@ -98,6 +98,7 @@ enum KnobId {
     KN_SWTF,               // 0: two-pass SWT instead of the fused per-level kernels
     KN_SWTF_M,             // fused SWT forward: rows per chunk (0 = auto)
     KN_SWTF_MI,            // fused SWT inverse: rows per chunk (0 = auto)
+    KN_SWTF_XCD,           // fused SWT levels: XCD-aware tile order
     KN_F64_FUSED,
     KN_F64_FUSED_MIN,      // fused long double-precision level kernels: smallest level side (pixels)
     KN_F64_LDS,            // LDS-ring form of the fused long double-precision level kernels (dwt_f64_lds.hip)
