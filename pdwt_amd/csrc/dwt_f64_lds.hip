@@ -25,6 +25,7 @@
 #include "dwt_f64_fused.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 #include "stream_dev.hpp"
@@ -349,10 +350,15 @@ int fwd2d_f64_lds(const double* in, double* cA, double* cH, double* cV, double* 
     int RO = idiv_up(idiv_up(nr2, chunks), 4) * 4;
     RO = std::max(RO, 4 * knob(KN_F64_LDS_MINGROUPS));
     chunks = idiv_up(nr2, RO);
-    static bool attr_done = false;
-    if (!attr_done) {
-        PDWT_HIP_TRY(hipFuncSetAttribute((const void*)k_fwd2d_f64lds<40>, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
-        attr_done = true;
+    {  // > 64 KB of dynamic LDS is opt-in, per device (one process may drive several: wt_batch.h)
+        static std::atomic<unsigned long long> done{0};
+        int dev = 0;
+        PDWT_HIP_TRY(hipGetDevice(&dev));
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done.load(std::memory_order_relaxed) & bit)) {
+            PDWT_HIP_TRY(hipFuncSetAttribute((const void*)k_fwd2d_f64lds<40>, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
+            done.fetch_or(bit, std::memory_order_relaxed);
+        }
     }
     TapTable tt;  // window position j meets { L[hlen-1-j], H[hlen-1-j] } (SURVEY A-1: out[i] = sum_j x[2i-c+j] F[hlen-1-j])
     for (int j = 0; j < hlen; j++) {
