@@ -352,6 +352,31 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
                         "step_compulsory_GBps": round(step_bytes / (gpu_ms / steps * 1e-3) / 1e9, 1),
                         "step_frac_of_peak": round(step_bytes / (gpu_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
 
+    if roofline is not None and rank == 0:
+        # What a plain device-to-device copy of the SAME byte volume reaches on this box, measured now (torch's copy kernel, half the
+        # bytes read + half written): the spec peak is not reachable by any stream here, and the reachable rate depends on whether
+        # the working set fits the 256 MB Infinity Cache (tools/copy_ceiling.py: 6.6-7.2 TB/s up to 256 MB moved, 4.7-4.9 TB/s beyond 1 GB).
+        try:
+            nbytes = int(roofline["algorithmic_bytes_per_launch"]) // 2
+            a_ = torch.empty(nbytes // 4, device="cuda", dtype=torch.float32).normal_()
+            b_ = torch.empty_like(a_)
+            for _ in range(3):
+                b_.copy_(a_)
+            torch.cuda.synchronize()
+            ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            creps = 30
+            ce0.record()
+            for _ in range(creps):
+                b_.copy_(a_)
+            ce1.record()
+            torch.cuda.synchronize()
+            cgbps = 2.0 * nbytes / (ce0.elapsed_time(ce1) * 1e-3 / creps) / 1e9
+            roofline["copy_ceiling"] = {"GBps": round(cgbps, 1), "bytes_moved": 2 * nbytes, "achieved_over_copy": round(roofline["achieved"] / cgbps, 4),
+                                        "what": "torch device-to-device copy of the dominant kernel's algorithmic byte volume, 30 repetitions, measured in this run"}
+            del a_, b_
+        except Exception as e:
+            roofline["copy_ceiling"] = {"error": repr(e)}
+
     if roofline is not None and cfg["dtype"] == "float64" and not cfg["do_swt"]:
         # long double-precision banks are FP64-VALU-bound on compulsory bytes -> also report the FP64 fraction.
         # forward FMAs per level = hlen*(2*r*c2 + 4*r2*c2) (2-D) or hlen*2*r*c2 (1-D); fwd+inv = 4x that in flop
