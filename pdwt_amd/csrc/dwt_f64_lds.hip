@@ -442,7 +442,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
     const int t_wr = lc * 16 + pair * 8;
     // chunk-local coefficient row k <-> band row p0 - C + k; rows past the last one the chunk needs are clamped (never consumed)
     const int klast = 2 * nsteps - 1 + H2 - 1;
-    auto grow = [&](int k) { return (size_t)wrapi(p0 - C + min(k, klast), Nri) * Nci; };
+    // (single conditional wrap: -C <= p0 - C + k < Nri + H2 + 2*kISB, and the dispatcher only sends levels with Nri >= 2*H2 here)
+    auto grow = [&](int k) { return (size_t)wrap1(p0 - C + min(k, klast), Nri) * Nci; };
     double r1[RS], r2[RS];
 #pragma unroll
     for (int k = 0; k < RS; k++) r1[k] = r2[k] = 0.0;
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
         if (s >= 1) {
             const int pl = 2 * (s - 1) + rg;  // chunk-local window position
             if (pl < np) {
-                const int row0 = wrapi(2 * (p0 + pl) - SHIFT, Nro);  // parity-1 row; the parity-0 row is the next one (periodic)
+                const int row0 = wrap1(2 * (p0 + pl) - SHIFT, Nro);  // parity-1 row; the parity-0 row is the next one (periodic)
                 const double o1a = x1l[0] + x1h[0], o0a = x0l[0] + x0h[0], o1b = x1l[1] + x1h[1], o0b = x0l[1] + x0h[1];
                 if (row0 + 1 < Nro) {  // uniform base + per-lane offset (the lane's row is part of the offset)
                     double* orow = out + (size_t)row0 * Nco;
@@ -637,7 +638,7 @@ int inv2d_f64_lds(const double* cA, const double* cH, const double* cV, const do
     if (knob(KN_F64_LDS) != 1) return 1;
     (void)taps_dev;
     if (hlen != 40) return 1;
-    if (nro != 2 * nri || nco != 2 * nci || nri < 2 || nci < 2) return 1;
+    if (nro != 2 * nri || nco != 2 * nci || nri < hlen || nci < 2) return 1;  // (row indices wrap at most once: wrap1)
     if ((long long)nro * nco < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
     const bool big = (long long)nro * nco >= 2048LL * 2048;
     const bool wide = big && knob(KN_F64_LDS_INV512) == 1;  // 512-thread workgroups: less halo, one workgroup per CU
