@@ -1,4 +1,5 @@
-// dwt_f64_lds.hip -- one 2-D DWT level per launch for LONG double-precision banks (db20: 40 taps), both passes fed from LDS.
+// dwt_f64_lds.hip -- one 2-D DWT level per launch for double-precision banks whose length is a multiple of 8 (written for db20:
+// 40 taps, the C5 configuration), both passes fed from LDS.
 //
 // Reference code replaced: w_kern_forward_pass1 + w_kern_forward_pass2 (src/separable.cu:91-176) of one iteration of
 // w_forward_separable (:179-209).
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
         double a0, h0, a1, h1;      // column pass: output rows 4g+rp, 4g+rp+2 of this plane
         // P[m] = samples 2m, 2m+1 of the row window (42 samples); Q[u] = ring rows k = 2u, 2u+1 of the column window (44 rows).
         // Section sec consumes P[4sec .. 4sec+4] and Q[4sec .. 4sec+5]; they are loaded one section AHEAD.
-        dbl2 P[21], Q[22];
+        dbl2 P[HLEN / 2 + 1], Q[HLEN / 2 + 2];
         auto ldP = [&](auto MM) {
             constexpr int m = decltype(MM)::value;
             P[m] = *reinterpret_cast<const dbl2*>(xr + m * 16);
@@ -333,15 +334,15 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
 // =================================================================================================
 #define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
 
-int fwd2d_f64_lds(const double* in, double* cA, double* cH, double* cV, double* cD, double* taps_dev, int nr, int nc, int hlen,
-                  const Taps2<double>& f)
+// filter lengths with an instantiation (sections of 8 taps; odd slot count of the staged rows): db4/sym4, db8/sym8,
+// db12/sym12/coif4, db16/sym16, db20/sym20.  Measured against the kernels they replace (two levels, 8192^2, forward / inverse):
+// db4 554/664 -> 283/378 us, db8 591/564 -> 312/421, db12 580/647 -> 442/435, db16 1089/1463 -> 477/495.
+#define PDWT_F64LDS_HLENS(X) X(8) X(16) X(24) X(32) X(40)
+
+template <int HLEN>
+static int launch_fwd_f64lds(const double* in, double* cA, double* cH, double* cV, double* cD, int nr, int nc, const Taps2<double>& f)
 {
-    if (knob(KN_F64_LDS) != 1) return 1;
-    (void)taps_dev;
-    if (hlen != 40) return 1;
-    using G = F64Lds<40>;
-    if ((nr & 1) || (nc & 1) || nr < 2 * kNIR || nc < 2) return 1;
-    if ((long long)nr * nc < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
+    using G = F64Lds<HLEN>;
     const int nr2 = nr / 2, nc2 = nc / 2;
     const int strips = idiv_up(nc2, kNCW);
     // two workgroups per CU when the level is large; one (steps run ~1.7x faster alone) when a chunk is mostly warm-up anyway
@@ -356,19 +357,38 @@ int fwd2d_f64_lds(const double* in, double* cA, double* cH, double* cV, double* 
         PDWT_HIP_TRY(hipGetDevice(&dev));
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(done.load(std::memory_order_relaxed) & bit)) {
-            PDWT_HIP_TRY(hipFuncSetAttribute((const void*)k_fwd2d_f64lds<40>, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
+            PDWT_HIP_TRY(hipFuncSetAttribute((const void*)k_fwd2d_f64lds<HLEN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
             done.fetch_or(bit, std::memory_order_relaxed);
         }
     }
     TapTable tt;  // window position j meets { L[hlen-1-j], H[hlen-1-j] } (SURVEY A-1: out[i] = sum_j x[2i-c+j] F[hlen-1-j])
-    for (int j = 0; j < hlen; j++) {
-        tt.t[2 * j] = f.a[hlen - 1 - j];
-        tt.t[2 * j + 1] = f.b[hlen - 1 - j];
+    for (int j = 0; j < HLEN; j++) {
+        tt.t[2 * j] = f.a[HLEN - 1 - j];
+        tt.t[2 * j + 1] = f.b[HLEN - 1 - j];
     }
     KTimer kt(K_FWD2D_F64);
-    hipLaunchKernelGGL((k_fwd2d_f64lds<40>), dim3(strips * chunks), dim3(kNT), G::kLdsBytes, stream(), tt, in, cA, cH, cV, cD, nr, nc, RO, strips);
+    constexpr size_t lds = G::kLdsBytes;
+    hipLaunchKernelGGL((k_fwd2d_f64lds<HLEN>), dim3(strips * chunks), dim3(kNT), lds, stream(), tt, in, cA, cH, cV, cD, nr, nc, RO, strips);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
+}
+
+static bool f64lds_len_ok(int hlen) { return hlen == 8 || hlen == 16 || hlen == 24 || hlen == 32 || hlen == 40; }
+
+int fwd2d_f64_lds(const double* in, double* cA, double* cH, double* cV, double* cD, double* taps_dev, int nr, int nc, int hlen,
+                  const Taps2<double>& f)
+{
+    if (knob(KN_F64_LDS) < 1 || !f64lds_len_ok(hlen)) return 1;
+    (void)taps_dev;
+    if ((nr & 1) || (nc & 1) || nr < 2 * kNIR || nc < 2) return 1;
+    if ((long long)nr * nc < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
+    switch (hlen) {
+#define X(H) \
+    case H: return launch_fwd_f64lds<H>(in, cA, cH, cV, cD, nr, nc, f);
+        PDWT_F64LDS_HLENS(X)
+#undef X
+        default: return 1;
+    }
 }
 
 // =================================================================================================
@@ -632,17 +652,14 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
     }
 }
 
-int inv2d_f64_lds(const double* cA, const double* cH, const double* cV, const double* cD, double* out, double* taps_dev, int nri, int nci,
-                  int nro, int nco, int hlen, const Taps2<double>& f)
+template <int HLEN>
+static int launch_inv_f64lds(const double* cA, const double* cH, const double* cV, const double* cD, double* out, int nri, int nci,
+                             const Taps2<double>& f)
 {
-    if (knob(KN_F64_LDS) != 1) return 1;
-    (void)taps_dev;
-    if (hlen != 40) return 1;
-    if (nro != 2 * nri || nco != 2 * nci || nri < hlen || nci < 2) return 1;  // (row indices wrap at most once: wrap1)
-    if ((long long)nro * nco < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
+    const int nro = 2 * nri, nco = 2 * nci;
     const bool big = (long long)nro * nco >= 2048LL * 2048;
     const bool wide = big && knob(KN_F64_LDS_INV512) == 1;  // 512-thread workgroups: less halo, one workgroup per CU
-    const int incw = wide ? F64Inv<40, 512>::INCW : F64Inv<40, 256>::INCW;
+    const int incw = wide ? F64Inv<HLEN, 512>::INCW : F64Inv<HLEN, 256>::INCW;
     const int strips = idiv_up(nci, incw);
     const int target = wide ? knob(KN_F64_LDS_WGS) / 2 : (big ? knob(KN_F64_LDS_WGS) : knob(KN_F64_LDS_WGS) / 2);
     int chunks = std::max(1, target / strips);
@@ -650,20 +667,36 @@ int inv2d_f64_lds(const double* cA, const double* cH, const double* cV, const do
     NP = std::max(NP, 2 * knob(KN_F64_LDS_MINGROUPS));
     chunks = idiv_up(nri, NP);
     TapTable tt;  // window position j meets { IL[h-2-2j], IL[h-1-2j], IH[h-2-2j], IH[h-1-2j] } (parity 1 / parity 0)
-    for (int j = 0; j < hlen / 2; j++) {
-        tt.t[4 * j + 0] = f.a[hlen - 2 - 2 * j];
-        tt.t[4 * j + 1] = f.a[hlen - 1 - 2 * j];
-        tt.t[4 * j + 2] = f.b[hlen - 2 - 2 * j];
-        tt.t[4 * j + 3] = f.b[hlen - 1 - 2 * j];
+    for (int j = 0; j < HLEN / 2; j++) {
+        tt.t[4 * j + 0] = f.a[HLEN - 2 - 2 * j];
+        tt.t[4 * j + 1] = f.a[HLEN - 1 - 2 * j];
+        tt.t[4 * j + 2] = f.b[HLEN - 2 - 2 * j];
+        tt.t[4 * j + 3] = f.b[HLEN - 1 - 2 * j];
     }
     KTimer kt(K_INV2D_F64);
-    constexpr size_t lds512 = F64Inv<40, 512>::kLdsBytes, lds256 = F64Inv<40, 256>::kLdsBytes;
+    constexpr size_t lds512 = F64Inv<HLEN, 512>::kLdsBytes, lds256 = F64Inv<HLEN, 256>::kLdsBytes;
     if (wide)
-        hipLaunchKernelGGL((k_inv2d_f64lds<40, 512>), dim3(strips * chunks), dim3(512), lds512, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP, strips);
+        hipLaunchKernelGGL((k_inv2d_f64lds<HLEN, 512>), dim3(strips * chunks), dim3(512), lds512, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP, strips);
     else
-        hipLaunchKernelGGL((k_inv2d_f64lds<40, 256>), dim3(strips * chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP, strips);
+        hipLaunchKernelGGL((k_inv2d_f64lds<HLEN, 256>), dim3(strips * chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP, strips);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
+}
+
+int inv2d_f64_lds(const double* cA, const double* cH, const double* cV, const double* cD, double* out, double* taps_dev, int nri, int nci,
+                  int nro, int nco, int hlen, const Taps2<double>& f)
+{
+    if (knob(KN_F64_LDS) < 1 || !f64lds_len_ok(hlen)) return 1;
+    (void)taps_dev;
+    if (nro != 2 * nri || nco != 2 * nci || nri < hlen || nci < 2) return 1;  // (row indices wrap at most once: wrap1)
+    if ((long long)nro * nco < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
+    switch (hlen) {
+#define X(H) \
+    case H: return launch_inv_f64lds<H>(cA, cH, cV, cD, out, nri, nci, f);
+        PDWT_F64LDS_HLENS(X)
+#undef X
+        default: return 1;
+    }
 }
 
 }  // namespace pdwt

@@ -791,6 +791,24 @@ def test_f64_long_filter_level_kernels_random_shapes():
                 assert np.array_equal(a, b), (nr, nc, lev, "band", k, "variant", other)
             assert np.array_equal(res[0][1], res[other][1]), (nr, nc, lev, "variant", other)
         assert band_err(res[0][1], x) <= 1e-10
+    # the other filter lengths these kernels are instantiated for (multiples of 8)
+    for wname, (nr, nc, lev) in (("db4", (1030, 516, 3)), ("sym8", (768, 1300, 3)), ("coif4", (520, 2050, 2)), ("db16", (1500, 640, 2)), ("sym20", (700, 900, 2))):
+        x = rs.uniform(-10, 10, (nr, nc))
+        res = []
+        for kn in (dict(), dict(f64_lds=0)):
+            with knobs(f64_lds_min=0, **kn):
+                W = pdwt_amd.Wavelets(x, wname, lev)
+                W.forward()
+                c = W.coeffs
+                W.inverse()
+                res.append((c, W.get_image()))
+        for k, (a, b) in enumerate(zip(res[0][0], res[1][0])):
+            assert np.array_equal(a, b), (wname, nr, nc, lev, "band", k)
+        assert np.array_equal(res[0][1], res[1][1]), (wname, nr, nc, lev)
+        O = orc.OracleWavelets(x, wname, lev)
+        O.forward()
+        for g, o in zip(res[0][0], O.coeffs):
+            assert band_err(g, o) <= 1e-10, wname
     x = rs.randn(600, 1112)
     with knobs(f64_lds_min=0):
         W, O = _pair(x, "db20", 3)

@@ -9,6 +9,8 @@ import pdwt_amd
 
 L = pdwt_amd.hip()
 lev = int(sys.argv[1])
+import os
+WN = os.environ.get("WNAME", "db20")
 
 
 def run(x, lev, **kn):
@@ -18,7 +20,7 @@ def run(x, lev, **kn):
         assert L.pdwt_debug_get(k.encode(), C.byref(cur)) == 0
         old[k] = cur.value
         L.pdwt_debug_set(k.encode(), v)
-    W = pdwt_amd.Wavelets(x.clone(), "db20", lev)
+    W = pdwt_amd.Wavelets(x.clone(), WN, lev)
     W.forward()
     W.sync()
     co = [torch.from_numpy(W.get_coeff(i)) for i in range(W.nbands)]
@@ -38,9 +40,9 @@ for a in sys.argv[2:]:
     c0, i0 = run(x, lev, force_twopass=1)
     bad = [k for k in range(len(c0)) if not torch.equal(c0[k], c1[k])]
     derr = max(float((p - q).abs().max()) for p, q in zip(c0, c1))
-    print("%dx%d L%d  bands differing: %s (max |d| %.3g)  image equal: %s (max |d| %.3g)  roundtrip %.3g" % (
+    print(WN, "%dx%d L%d  bands differing: %s (max |d| %.3g)  image equal: %s (max |d| %.3g)  roundtrip %.3g" % (
         nr, nc, lev, bad, derr, torch.equal(i0, i1), float((i0 - i1).abs().max()), float((i1 - x.cpu()).abs().max())), flush=True)
-    W = pdwt_amd.Wavelets(x, "db20", lev)
+    W = pdwt_amd.Wavelets(x, WN, lev)
     reps = max(5, min(200, int(2e8 / (nr * nc))))
     for _ in range(3):
         W.forward(); W.inverse()
