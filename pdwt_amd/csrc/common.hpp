@@ -105,7 +105,6 @@ enum KnobId {
     KN_F64_LDS_MIN,        // ... smallest level side (pixels)
     KN_F64_LDS_WGS,        // ... workgroups to aim for
     KN_F64_LDS_MINGROUPS,  // ... shortest chunk, in groups of 4 output rows
-    KN_F64_LDS_INV512,     // ... inverse: 512-thread workgroups on the large levels
     KN_NORM2SQ_REF1D,      // 1: norm2sq of a 1-D transform adds sum|d| of the detail bands like the reference (src/wt.cu:389) instead of sum d^2          // 0: two-pass form for long double-precision 2D levels instead of the fused row+column kernels
     KN_COUNT
 };

@@ -417,7 +417,8 @@ constexpr int kISB = 4;     // steps per unrolled body (ring slots are compile-t
 }  // namespace
 
 // NT threads per workgroup: NT/2 per band pair = coefficient columns whose t values the workgroup computes; H2-1 of them are halo.
-// NT = 256: 108 columns produced (17.6 % of the column synthesis is halo), two workgroups per CU; NT = 512: 236 columns (8 %), one.
+// NT = 256: 108 columns produced at db20 (17.6 % of the column synthesis is halo), two workgroups per CU.  (NT = 512 -- 236 columns,
+// 8 % halo, one workgroup per CU -- measured the same time and is not instantiated.)
 template <int HLEN, int NT>
 struct F64Inv {
     static constexpr int H2 = HLEN / 2, C = H2 / 2, SHIFT = (H2 & 1) ? 0 : 1;
@@ -658,10 +659,8 @@ static int launch_inv_f64lds(const double* cA, const double* cH, const double* c
 {
     const int nro = 2 * nri, nco = 2 * nci;
     const bool big = (long long)nro * nco >= 2048LL * 2048;
-    const bool wide = big && knob(KN_F64_LDS_INV512) == 1;  // 512-thread workgroups: less halo, one workgroup per CU
-    const int incw = wide ? F64Inv<HLEN, 512>::INCW : F64Inv<HLEN, 256>::INCW;
-    const int strips = idiv_up(nci, incw);
-    const int target = wide ? knob(KN_F64_LDS_WGS) / 2 : (big ? knob(KN_F64_LDS_WGS) : knob(KN_F64_LDS_WGS) / 2);
+    const int strips = idiv_up(nci, F64Inv<HLEN, 256>::INCW);
+    const int target = big ? knob(KN_F64_LDS_WGS) : knob(KN_F64_LDS_WGS) / 2;
     int chunks = std::max(1, target / strips);
     int NP = idiv_up(idiv_up(nri, chunks), 2) * 2;
     NP = std::max(NP, 2 * knob(KN_F64_LDS_MINGROUPS));
@@ -674,11 +673,8 @@ static int launch_inv_f64lds(const double* cA, const double* cH, const double* c
         tt.t[4 * j + 3] = f.b[HLEN - 1 - 2 * j];
     }
     KTimer kt(K_INV2D_F64);
-    constexpr size_t lds512 = F64Inv<HLEN, 512>::kLdsBytes, lds256 = F64Inv<HLEN, 256>::kLdsBytes;
-    if (wide)
-        hipLaunchKernelGGL((k_inv2d_f64lds<HLEN, 512>), dim3(strips * chunks), dim3(512), lds512, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP, strips);
-    else
-        hipLaunchKernelGGL((k_inv2d_f64lds<HLEN, 256>), dim3(strips * chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP, strips);
+    constexpr size_t lds256 = F64Inv<HLEN, 256>::kLdsBytes;
+    hipLaunchKernelGGL((k_inv2d_f64lds<HLEN, 256>), dim3(strips * chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP, strips);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
