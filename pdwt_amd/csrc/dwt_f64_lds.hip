@@ -339,8 +339,12 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
 // db4 554/664 -> 283/378 us, db8 591/564 -> 312/421, db12 580/647 -> 442/435, db16 1089/1463 -> 477/495.
 #define PDWT_F64LDS_HLENS(X) X(8) X(16) X(24) X(32) X(40)
 
+// HLEN = the instantiated length, hlen <= HLEN the filter's own (even) length: the bank is zero-padded SYMMETRICALLY, q = (HLEN-hlen)/2
+// taps at either end.  out[i] = sum_j x[2i - C + j] F[hlen-1-j] with C = hlen/2 - 1 becomes the same sum over the padded window
+// (C' = C + q, the original taps at positions q .. q+hlen-1); the extra terms are fma(x, 0, acc) = acc, so the result is the one
+// of the unpadded filter bit for bit (finite data).
 template <int HLEN>
-static int launch_fwd_f64lds(const double* in, double* cA, double* cH, double* cV, double* cD, int nr, int nc, const Taps2<double>& f)
+static int launch_fwd_f64lds(const double* in, double* cA, double* cH, double* cV, double* cD, int nr, int nc, int hlen, const Taps2<double>& f)
 {
     using G = F64Lds<HLEN>;
     const int nr2 = nr / 2, nc2 = nc / 2;
@@ -362,9 +366,12 @@ static int launch_fwd_f64lds(const double* in, double* cA, double* cH, double* c
         }
     }
     TapTable tt;  // window position j meets { L[hlen-1-j], H[hlen-1-j] } (SURVEY A-1: out[i] = sum_j x[2i-c+j] F[hlen-1-j])
+    const int q = (HLEN - hlen) / 2;
     for (int j = 0; j < HLEN; j++) {
-        tt.t[2 * j] = f.a[HLEN - 1 - j];
-        tt.t[2 * j + 1] = f.b[HLEN - 1 - j];
+        const int k = j - q;
+        const bool in_bank = k >= 0 && k < hlen;
+        tt.t[2 * j] = in_bank ? f.a[hlen - 1 - k] : 0.0;
+        tt.t[2 * j + 1] = in_bank ? f.b[hlen - 1 - k] : 0.0;
     }
     KTimer kt(K_FWD2D_F64);
     constexpr size_t lds = G::kLdsBytes;
@@ -373,18 +380,20 @@ static int launch_fwd_f64lds(const double* in, double* cA, double* cH, double* c
     return PDWT_OK;
 }
 
-static bool f64lds_len_ok(int hlen) { return hlen == 8 || hlen == 16 || hlen == 24 || hlen == 32 || hlen == 40; }
+// every EVEN filter length up to 40 runs the next instantiated length (zero-padded, see launch_fwd_f64lds)
+static int f64lds_padded_len(int hlen) { return (hlen >= 2 && hlen <= 40 && !(hlen & 1)) ? (hlen + 7) / 8 * 8 : 0; }
 
 int fwd2d_f64_lds(const double* in, double* cA, double* cH, double* cV, double* cD, double* taps_dev, int nr, int nc, int hlen,
                   const Taps2<double>& f)
 {
-    if (knob(KN_F64_LDS) < 1 || !f64lds_len_ok(hlen)) return 1;
+    const int hp = f64lds_padded_len(hlen);
+    if (knob(KN_F64_LDS) < 1 || !hp || (hp != hlen && knob(KN_F64_LDS) == 3)) return 1;  // (3: exact lengths only)
     (void)taps_dev;
-    if ((nr & 1) || (nc & 1) || nr < 2 * kNIR || nc < 2) return 1;
+    if ((nr & 1) || (nc & 1) || nr < 2 * kNIR || nr < hp || nc < hp) return 1;
     if ((long long)nr * nc < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
-    switch (hlen) {
+    switch (hp) {
 #define X(H) \
-    case H: return launch_fwd_f64lds<H>(in, cA, cH, cV, cD, nr, nc, f);
+    case H: return launch_fwd_f64lds<H>(in, cA, cH, cV, cD, nr, nc, hlen, f);
         PDWT_F64LDS_HLENS(X)
 #undef X
         default: return 1;
@@ -653,8 +662,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
     }
 }
 
+// (zero-padded like the forward bank: out[n] = sum_k c[k] IL[n - 2k + hlen/2 - 1], so q = (HLEN-hlen)/2 zeros in FRONT of the bank
+// keep every product where it was)
 template <int HLEN>
-static int launch_inv_f64lds(const double* cA, const double* cH, const double* cV, const double* cD, double* out, int nri, int nci,
+static int launch_inv_f64lds(const double* cA, const double* cH, const double* cV, const double* cD, double* out, int nri, int nci, int hlen,
                              const Taps2<double>& f)
 {
     const int nro = 2 * nri, nco = 2 * nci;
@@ -666,11 +677,13 @@ static int launch_inv_f64lds(const double* cA, const double* cH, const double* c
     NP = std::max(NP, 2 * knob(KN_F64_LDS_MINGROUPS));
     chunks = idiv_up(nri, NP);
     TapTable tt;  // window position j meets { IL[h-2-2j], IL[h-1-2j], IH[h-2-2j], IH[h-1-2j] } (parity 1 / parity 0)
+    const int q = (HLEN - hlen) / 2;
+    auto pad = [&](const double* bank, int t) { return (t - q >= 0 && t - q < hlen) ? bank[t - q] : 0.0; };
     for (int j = 0; j < HLEN / 2; j++) {
-        tt.t[4 * j + 0] = f.a[HLEN - 2 - 2 * j];
-        tt.t[4 * j + 1] = f.a[HLEN - 1 - 2 * j];
-        tt.t[4 * j + 2] = f.b[HLEN - 2 - 2 * j];
-        tt.t[4 * j + 3] = f.b[HLEN - 1 - 2 * j];
+        tt.t[4 * j + 0] = pad(f.a, HLEN - 2 - 2 * j);
+        tt.t[4 * j + 1] = pad(f.a, HLEN - 1 - 2 * j);
+        tt.t[4 * j + 2] = pad(f.b, HLEN - 2 - 2 * j);
+        tt.t[4 * j + 3] = pad(f.b, HLEN - 1 - 2 * j);
     }
     KTimer kt(K_INV2D_F64);
     constexpr size_t lds256 = F64Inv<HLEN, 256>::kLdsBytes;
@@ -682,13 +695,14 @@ static int launch_inv_f64lds(const double* cA, const double* cH, const double* c
 int inv2d_f64_lds(const double* cA, const double* cH, const double* cV, const double* cD, double* out, double* taps_dev, int nri, int nci,
                   int nro, int nco, int hlen, const Taps2<double>& f)
 {
-    if (knob(KN_F64_LDS) < 1 || !f64lds_len_ok(hlen)) return 1;
+    const int hp = f64lds_padded_len(hlen);
+    if (knob(KN_F64_LDS) < 1 || !hp || (hp != hlen && knob(KN_F64_LDS) == 3)) return 1;
     (void)taps_dev;
-    if (nro != 2 * nri || nco != 2 * nci || nri < hlen || nci < 2) return 1;  // (row indices wrap at most once: wrap1)
+    if (nro != 2 * nri || nco != 2 * nci || nri < hp || nci < 2) return 1;  // (row indices wrap at most once: wrap1)
     if ((long long)nro * nco < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
-    switch (hlen) {
+    switch (hp) {
 #define X(H) \
-    case H: return launch_inv_f64lds<H>(cA, cH, cV, cD, out, nri, nci, f);
+    case H: return launch_inv_f64lds<H>(cA, cH, cV, cD, out, nri, nci, hlen, f);
         PDWT_F64LDS_HLENS(X)
 #undef X
         default: return 1;

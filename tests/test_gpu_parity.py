@@ -809,6 +809,22 @@ def test_f64_long_filter_level_kernels_random_shapes():
         O.forward()
         for g, o in zip(res[0][0], O.coeffs):
             assert band_err(g, o) <= 1e-10, wname
+    # every other even length runs the next multiple of 8 with a symmetrically zero-padded bank: same sums, bit for bit
+    for wname in ("db2", "db5", "db7", "db10", "db13", "sym9", "coif3", "coif5", "bior2.4", "bior3.7", "rbio3.9"):
+        nr, nc, lev = 2 * rs.randint(120, 600), 2 * rs.randint(120, 600), rs.randint(1, 4)
+        x = rs.uniform(-10, 10, (nr, nc))
+        res = []
+        for kn in (dict(), dict(f64_lds=3)):  # 3: exact lengths only
+            with knobs(f64_lds_min=0, **kn):
+                W = pdwt_amd.Wavelets(x, wname, lev)
+                W.forward()
+                c = W.coeffs
+                W.inverse()
+                res.append((c, W.get_image()))
+        for k, (a, b) in enumerate(zip(res[0][0], res[1][0])):
+            assert np.array_equal(a, b), (wname, nr, nc, lev, "band", k)
+        assert np.array_equal(res[0][1], res[1][1]), (wname, nr, nc, lev)
+        assert band_err(res[0][1], x) <= 1e-9, wname
     x = rs.randn(600, 1112)
     with knobs(f64_lds_min=0):
         W, O = _pair(x, "db20", 3)
