@@ -101,7 +101,7 @@ enum KnobId {
     KN_SWTF_XCD,           // fused SWT levels: XCD-aware tile order
     KN_F64_FUSED,
     KN_F64_FUSED_MIN,      // fused long double-precision level kernels: smallest level side (pixels)
-    KN_F64_LDS,            // LDS-ring form of the fused long double-precision level kernels (dwt_f64_lds.hip)
+    KN_F64_LDS,            // LDS-ring form of the fused long double-precision level kernels (dwt_lds.hip)
     KN_F64_LDS_MIN,        // ... smallest level side (pixels)
     KN_F64_LDS_WGS,        // ... workgroups to aim for
     KN_F64_LDS_MINGROUPS,  // ... shortest chunk, in groups of 4 output rows

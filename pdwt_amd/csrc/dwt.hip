@@ -571,7 +571,9 @@ static int level_fwd2d(const T* in, T* cA, T* cH, T* cV, T* cD, T* t1, T* t2, si
         if (!force_twopass()) {
             // t1 (the two-pass scratch, sized for the FULL image) is unused on this path: it serves as the trash area of
             // the streaming kernels whenever it is big enough
-            const int rc = fwd2d_stream_f32(in, cA, cH, cV, cD, (float*)t1, trash_floats, nr, nc, hlen, f);
+            int rc = fwd2d_stream_f32(in, cA, cH, cV, cD, (float*)t1, trash_floats, nr, nc, hlen, f);
+            if (rc <= 0) return rc;
+            rc = fwd2d_f32_lds(in, cA, cH, cV, cD, nr, nc, hlen, f);  // long banks: both passes of the level in one launch (dwt_lds.hip)
             if (rc <= 0) return rc;
         }
     }
@@ -610,7 +612,9 @@ static int level_inv2d(const T* cA, const T* cH, const T* cV, const T* cD, T* ou
     }
     if constexpr (sizeof(T) == 4) {
         if (!force_twopass()) {
-            const int rc = inv2d_stream_f32(cA, cH, cV, cD, out, nri, nci, nro, nco, hlen, f);
+            int rc = inv2d_stream_f32(cA, cH, cV, cD, out, nri, nci, nro, nco, hlen, f);
+            if (rc <= 0) return rc;
+            rc = inv2d_f32_lds(cA, cH, cV, cD, out, nri, nci, nro, nco, hlen, f);
             if (rc <= 0) return rc;
         }
     }

@@ -1,5 +1,6 @@
-// dwt_f64_lds.hip -- one 2-D DWT level per launch for double-precision banks whose length is a multiple of 8 (written for db20:
-// 40 taps, the C5 configuration), both passes fed from LDS.
+// dwt_lds.hip -- one 2-D DWT level per launch with both passes fed from LDS: every double-precision bank of even length and the
+// float32 banks of more than 16 taps (written for db20 in double, 40 taps: the C5 configuration; other lengths run the next
+// multiple of 8, zero-padded).
 //
 // Reference code replaced: w_kern_forward_pass1 + w_kern_forward_pass2 (src/separable.cu:91-176) of one iteration of
 // w_forward_separable (:179-209).
@@ -40,22 +41,24 @@ constexpr int kNIR = 8;       // input rows per step (= 4 output rows)
 constexpr int kRing = 56;     // ring rows in LDS: window of 46 rows (two output rows + their neighbours) + the 8 rows being written
 constexpr int kPhases = 7;    // kRing / kNIR
 constexpr int kLag = 6;       // the column pass of step s emits output rows 4(s-kLag) .. +3
-typedef const double __attribute__((address_space(4))) * ctaps_t;
-typedef double dbl2 __attribute__((ext_vector_type(2)));  // a register pair the inline asm can take as ONE operand
+template <typename T> using ctaps_t = const T __attribute__((address_space(4))) *;
+template <typename T> using pair_t = T __attribute__((ext_vector_type(2)));  // a register pair the inline asm can take as ONE operand
 // The taps, in the order the kernels consume them, travel as the FIRST kernel argument: the kernarg segment is constant memory, so
 // the sections' scalar loads read it directly (no staging launch, no device scratch).
+template <typename T>
 struct TapTable {
-    double t[2 * PDWT_MAX_FILTER_WIDTH];
+    T t[2 * PDWT_MAX_FILTER_WIDTH];
 };
-__device__ __forceinline__ ctaps_t kernarg_taps() { return (ctaps_t)__builtin_amdgcn_kernarg_segment_ptr(); }
+template <typename T> __device__ __forceinline__ ctaps_t<T> kernarg_taps() { return (ctaps_t<T>)__builtin_amdgcn_kernarg_segment_ptr(); }
 // uniform base (SGPR pair) + per-lane 32-bit BYTE offset: the addressing mode that needs no 64-bit vector arithmetic per access
-__device__ __forceinline__ double ld_sv(const double* base, unsigned boff)
+template <typename T>
+__device__ __forceinline__ T ld_sv(const T* base, unsigned boff)
 {
     typedef const char __attribute__((address_space(1))) * gbytes_t;
-    typedef const double __attribute__((address_space(1))) * gdbl_t;
+    typedef const T __attribute__((address_space(1))) * gelem_t;
     // opaque to the optimiser: keeps hipcc from folding the per-lane offset into a loop-invariant 64-bit VGPR pointer
     asm("" : "+s"(base));
-    return *(gdbl_t)((gbytes_t)base + boff);
+    return *(gelem_t)((gbytes_t)base + boff);
 }
 // Workgroup id -> (strip, chunk), XCD-aware.  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs; every
 // XCD is given a CONTIGUOUS run of the strip-major tile order instead, so that horizontally adjacent strips -- whose input windows
@@ -72,16 +75,23 @@ __device__ __forceinline__ void st_sv(double* base, unsigned boff, double v)
 {
     asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(boff), "v"(v), "s"(base) : "memory");
 }
+__device__ __forceinline__ void st_sv(float* base, unsigned boff, float v)
+{
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(boff), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void st_flat(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_flat(float* p, float v) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 }  // namespace
 
-template <int HLEN>
+template <typename T, int HLEN>
 struct F64Lds {
+    static constexpr int ES = sizeof(T);
     static constexpr int C = HLEN / 2 - 1;
-    static constexpr int LWI = 2 * kNCW + HLEN - 2;  // input columns staged per row (doubles)
-    static constexpr int PAIRS = LWI / 2;            // 16-byte slots per staged row; must be odd (bank spreading, see above)
-    static constexpr int kColStride = (kRing + 2) * 8;          // ring planes are column-major: [column][ring row], + mirror of rows 0, 1
+    static constexpr int LWI = 2 * kNCW + HLEN - 2;  // input columns staged per row (elements)
+    static constexpr int PAIRS = LWI / 2;            // two-element slots per staged row; must be odd (bank spreading, see above)
+    static constexpr int kColStride = (kRing + 2) * ES;          // ring planes are column-major: [column][ring row], + mirror of rows 0, 1
     static constexpr int kPlaneBytes = kColStride * kNCW;
-    static constexpr int kInBufBytes = kNIR * LWI * 8;
+    static constexpr int kInBufBytes = kNIR * LWI * ES;
     static constexpr int kLdsBytes = 2 * kPlaneBytes + 2 * kInBufBytes;
     static_assert(PAIRS % 2 == 1, "staged rows must be an odd number of 16-byte slots apart");
     static_assert(HLEN % 8 == 0, "sections of 8 taps");
@@ -90,12 +100,14 @@ struct F64Lds {
     static_assert(kNIR * (kLag + 1) - kRing <= 2, "the rows a step writes must not be part of the windows it reads");
 };
 
-template <int HLEN>
-__global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through kernarg_taps()*/, const double* __restrict__ in,
-                                                          double* __restrict__ cA, double* __restrict__ cH, double* __restrict__ cV,
-                                                          double* __restrict__ cD, int Nr, int Nc, int RO, int strips)
+template <typename T, int HLEN>
+__global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read through kernarg_taps()*/, const T* __restrict__ in,
+                                                          T* __restrict__ cA, T* __restrict__ cH, T* __restrict__ cV,
+                                                          T* __restrict__ cD, int Nr, int Nc, int RO, int strips)
 {
-    using G = F64Lds<HLEN>;
+    using G = F64Lds<T, HLEN>;
+    using V2 = pair_t<T>;
+    constexpr int ES = sizeof(T);
     constexpr int C = G::C, LWI = G::LWI, PAIRS = G::PAIRS;
     constexpr int NSEC = HLEN / 8;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -116,17 +128,17 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
     unsigned gc[3][2];  // byte offsets within an image row
 #pragma unroll
     for (int m = 0; m < 3; m++) {
-        gc[m][0] = 8u * (unsigned)wrapi(cbase + 2 * (k0 + 32 * m), Nc);
-        gc[m][1] = 8u * (unsigned)wrapi(cbase + 2 * (k0 + 32 * m) + 1, Nc);
+        gc[m][0] = (unsigned)ES * (unsigned)wrapi(cbase + 2 * (k0 + 32 * m), Nc);
+        gc[m][1] = (unsigned)ES * (unsigned)wrapi(cbase + 2 * (k0 + 32 * m) + 1, Nc);
     }
-    const unsigned rowb = 8u * (unsigned)Nc * (unsigned)srow;  // the thread's row within the 8 rows of a step (when they do not wrap)
+    const unsigned rowb = (unsigned)ES * (unsigned)Nc * (unsigned)srow;  // the thread's row within the 8 rows of a step (when they do not wrap)
     const bool third = k0 + 64 < PAIRS;
     // chunk-local row rho <-> image row 2*y0 - C - 2 + rho (two leading rows align the output groups with the steps)
     int rnext = wrapi(2 * y0 - C - 2, Nr);  // image row of rho = 8*(step to stage)
-    double st[3][2];
+    T st[3][2];
     auto load_rows = [&]() {
         if (rnext + kNIR <= Nr) {  // the step's 8 rows are consecutive: uniform base + 32-bit per-lane offset
-            const double* p = in + (size_t)rnext * Nc;
+            const T* p = in + (size_t)rnext * Nc;
             st[0][0] = ld_sv(p, rowb + gc[0][0]);
             st[0][1] = ld_sv(p, rowb + gc[0][1]);
             st[1][0] = ld_sv(p, rowb + gc[1][0]);
@@ -138,43 +150,43 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
         } else {  // (uniform; at most two steps of a chunk) they wrap around the bottom edge: per-lane 64-bit row pointers
             const int r = rnext + srow;
             const char* p = reinterpret_cast<const char*>(in + (size_t)(r >= Nr ? r - Nr : r) * Nc);
-            st[0][0] = *reinterpret_cast<const double*>(p + gc[0][0]);
-            st[0][1] = *reinterpret_cast<const double*>(p + gc[0][1]);
-            st[1][0] = *reinterpret_cast<const double*>(p + gc[1][0]);
-            st[1][1] = *reinterpret_cast<const double*>(p + gc[1][1]);
+            st[0][0] = *reinterpret_cast<const T*>(p + gc[0][0]);
+            st[0][1] = *reinterpret_cast<const T*>(p + gc[0][1]);
+            st[1][0] = *reinterpret_cast<const T*>(p + gc[1][0]);
+            st[1][1] = *reinterpret_cast<const T*>(p + gc[1][1]);
             if (third) {
-                st[2][0] = *reinterpret_cast<const double*>(p + gc[2][0]);
-                st[2][1] = *reinterpret_cast<const double*>(p + gc[2][1]);
+                st[2][0] = *reinterpret_cast<const T*>(p + gc[2][0]);
+                st[2][1] = *reinterpret_cast<const T*>(p + gc[2][1]);
             }
         }
         rnext += kNIR;
         rnext = rnext >= Nr ? rnext - Nr : rnext;
     };
     char* const in_lds = lds_raw + 2 * G::kPlaneBytes;
-    int stage_off = srow * LWI * 8 + k0 * 16;  // within an input buffer
+    int stage_off = srow * LWI * ES + k0 * 2 * ES;  // within an input buffer
     auto store_rows = [&](int buf) {
         char* b = in_lds + buf * G::kInBufBytes + stage_off;
-        *reinterpret_cast<double2*>(b) = make_double2(st[0][0], st[0][1]);
-        *reinterpret_cast<double2*>(b + 512) = make_double2(st[1][0], st[1][1]);
-        if (third) *reinterpret_cast<double2*>(b + 1024) = make_double2(st[2][0], st[2][1]);
+        *reinterpret_cast<V2*>(b) = V2{st[0][0], st[0][1]};
+        *reinterpret_cast<V2*>(b + 32 * 2 * ES) = V2{st[1][0], st[1][1]};
+        if (third) *reinterpret_cast<V2*>(b + 64 * 2 * ES) = V2{st[2][0], st[2][1]};
     };
 
     // ---- row-pass role: lane -> (row bit, column pair); every 16-lane LDS group holds 8 windows of each of the wave's two rows
     const int rbit = (lane >> 3) & 1;
     const int cp = (((lane >> 5) & 1) << 4) | (((lane >> 2) & 1) << 3) | (((lane >> 4) & 1) << 2) | (lane & 3);
     const int rrow = 2 * w + rbit;
-    const int row_rd = rrow * LWI * 8 + cp * 32;             // window of output column 2cp starts at LDS column 4cp
-    const int row_wr = 2 * cp * G::kColStride + rrow * 8;     // ring row (8*phase + rrow), columns 2cp, 2cp+1 (lo plane; hi plane + kPlaneBytes)
+    const int row_rd = rrow * LWI * ES + cp * 4 * ES;             // window of output column 2cp starts at LDS column 4cp
+    const int row_wr = 2 * cp * G::kColStride + rrow * ES;     // ring row (8*phase + rrow), columns 2cp, 2cp+1 (lo plane; hi plane + kPlaneBytes)
     // ---- column-pass role: wave -> (plane, row pair), lane -> column
     const int plane = w & 1, rp = w >> 1;
-    const char* const col_rd = lds_raw + plane * G::kPlaneBytes + lane * G::kColStride + rp * 16;
-    double* const outL = plane ? cV : cA;
-    double* const outH = plane ? cD : cH;
+    const char* const col_rd = lds_raw + plane * G::kPlaneBytes + lane * G::kColStride + rp * 2 * ES;
+    T* const outL = plane ? cV : cA;
+    T* const outH = plane ? cD : cH;
     const bool col_ok = i0 + lane < Nc2;
-    const unsigned ocol = 8u * (unsigned)(i0 + lane);
+    const unsigned ocol = (unsigned)ES * (unsigned)(i0 + lane);
 
-    ctaps_t tbase = kernarg_taps();
-    double tl[2][8], th[2][8];
+    ctaps_t<T> tbase = kernarg_taps<T>();
+    T tl[2][8], th[2][8];
 #pragma unroll
     for (int jj = 0; jj < 8; jj++) {
         tl[0][jj] = tbase[2 * jj];
@@ -191,18 +203,18 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
         const int buf = s & 1;
         load_rows();  // rows of step s+1, in flight while this step computes
         const char* xr = in_lds + buf * G::kInBufBytes + row_rd;
-        double lo0, hi0, lo1, hi1;  // row pass: output columns 2cp, 2cp+1 of row rrow
-        double a0, h0, a1, h1;      // column pass: output rows 4g+rp, 4g+rp+2 of this plane
+        T lo0, hi0, lo1, hi1;  // row pass: output columns 2cp, 2cp+1 of row rrow
+        T a0, h0, a1, h1;      // column pass: output rows 4g+rp, 4g+rp+2 of this plane
         // P[m] = samples 2m, 2m+1 of the row window (42 samples); Q[u] = ring rows k = 2u, 2u+1 of the column window (44 rows).
         // Section sec consumes P[4sec .. 4sec+4] and Q[4sec .. 4sec+5]; they are loaded one section AHEAD.
-        dbl2 P[HLEN / 2 + 1], Q[HLEN / 2 + 2];
+        V2 P[HLEN / 2 + 1], Q[HLEN / 2 + 2];
         auto ldP = [&](auto MM) {
             constexpr int m = decltype(MM)::value;
-            P[m] = *reinterpret_cast<const dbl2*>(xr + m * 16);
+            P[m] = *reinterpret_cast<const V2*>(xr + m * 2 * ES);
         };
         auto ldQ = [&](auto UU) {
             constexpr int u = decltype(UU)::value;
-            Q[u] = *reinterpret_cast<const dbl2*>(col_rd + ((cbase_row + 2 * u) % kRing) * 8);
+            Q[u] = *reinterpret_cast<const V2*>(col_rd + ((cbase_row + 2 * u) % kRing) * ES);
         };
         static_for<5>([&](auto MM) { ldP(MM); });
         static_for<6>([&](auto UU) { ldQ(UU); });
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
             // Ordering point.  Everything this section consumes (its LDS data and its taps) passes through the statement, so the
             // one wait it needs -- lgkmcnt(0): scalar loads return out of order -- sits HERE, before the next section's loads are
             // issued, and nothing further has to be waited for until the next ordering point.
-            ctaps_t tp = tbase;
+            ctaps_t<T> tp = tbase;
             if constexpr (sec == 0)
                 asm volatile(""
                              : "+s"(tp), "+v"(P[0]), "+v"(Q[0]), "+v"(Q[1]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]), "+v"(P[4]), "+v"(Q[2]), "+v"(Q[3]),
@@ -238,22 +250,22 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
             static_for<4>([&](auto MM) {
                 constexpr int m = decltype(MM)::value;
                 constexpr int jj = 2 * m;
-                const dbl2 p = P[4 * sec + m], q = P[4 * sec + m + 1];
+                const V2 p = P[4 * sec + m], q = P[4 * sec + m + 1];
                 if constexpr (sec == 0 && m == 0) {  // fma(x, t, 0) == x * t: no zero-initialisation moves
                     lo0 = p.x * tl[cur][jj];
                     hi0 = p.x * th[cur][jj];
                     lo1 = q.x * tl[cur][jj];
                     hi1 = q.x * th[cur][jj];
                 } else {
-                    lo0 = __builtin_fma(p.x, tl[cur][jj], lo0);
-                    hi0 = __builtin_fma(p.x, th[cur][jj], hi0);
-                    lo1 = __builtin_fma(q.x, tl[cur][jj], lo1);
-                    hi1 = __builtin_fma(q.x, th[cur][jj], hi1);
+                    lo0 = fma_t<T>(p.x, tl[cur][jj], lo0);
+                    hi0 = fma_t<T>(p.x, th[cur][jj], hi0);
+                    lo1 = fma_t<T>(q.x, tl[cur][jj], lo1);
+                    hi1 = fma_t<T>(q.x, th[cur][jj], hi1);
                 }
-                lo0 = __builtin_fma(p.y, tl[cur][jj + 1], lo0);
-                hi0 = __builtin_fma(p.y, th[cur][jj + 1], hi0);
-                lo1 = __builtin_fma(q.y, tl[cur][jj + 1], lo1);
-                hi1 = __builtin_fma(q.y, th[cur][jj + 1], hi1);
+                lo0 = fma_t<T>(p.y, tl[cur][jj + 1], lo0);
+                hi0 = fma_t<T>(p.y, th[cur][jj + 1], hi0);
+                lo1 = fma_t<T>(q.y, tl[cur][jj + 1], lo1);
+                hi1 = fma_t<T>(q.y, th[cur][jj + 1], hi1);
             });
             // column pass: output rows 4g+rp and 4g+rp+2 (g = s-kLag); ring rows rho = 8g + 2 + 2rp + k, tap j meets k = j (first
             // row) and k = j+4 (second row).  (During the first kLag steps of a chunk this works on rows that do not exist yet; nothing
@@ -261,37 +273,37 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
             static_for<4>([&](auto MM) {
                 constexpr int m = decltype(MM)::value;
                 constexpr int jj = 2 * m;
-                const dbl2 p = Q[4 * sec + m], q = Q[4 * sec + m + 2];
+                const V2 p = Q[4 * sec + m], q = Q[4 * sec + m + 2];
                 if constexpr (sec == 0 && m == 0) {
                     a0 = p.x * tl[cur][jj];
                     h0 = p.x * th[cur][jj];
                     a1 = q.x * tl[cur][jj];
                     h1 = q.x * th[cur][jj];
                 } else {
-                    a0 = __builtin_fma(p.x, tl[cur][jj], a0);
-                    h0 = __builtin_fma(p.x, th[cur][jj], h0);
-                    a1 = __builtin_fma(q.x, tl[cur][jj], a1);
-                    h1 = __builtin_fma(q.x, th[cur][jj], h1);
+                    a0 = fma_t<T>(p.x, tl[cur][jj], a0);
+                    h0 = fma_t<T>(p.x, th[cur][jj], h0);
+                    a1 = fma_t<T>(q.x, tl[cur][jj], a1);
+                    h1 = fma_t<T>(q.x, th[cur][jj], h1);
                 }
-                a0 = __builtin_fma(p.y, tl[cur][jj + 1], a0);
-                h0 = __builtin_fma(p.y, th[cur][jj + 1], h0);
-                a1 = __builtin_fma(q.y, tl[cur][jj + 1], a1);
-                h1 = __builtin_fma(q.y, th[cur][jj + 1], h1);
+                a0 = fma_t<T>(p.y, tl[cur][jj + 1], a0);
+                h0 = fma_t<T>(p.y, th[cur][jj + 1], h0);
+                a1 = fma_t<T>(q.y, tl[cur][jj + 1], a1);
+                h1 = fma_t<T>(q.y, th[cur][jj + 1], h1);
             });
         });
         // new ring rows 8*PH + rrow (ring planes are stored column-major: the column pass reads two rows per 16 bytes)
         {
-            char* wr = lds_raw + PH * kNIR * 8 + row_wr;
-            *reinterpret_cast<double*>(wr) = lo0;
-            *reinterpret_cast<double*>(wr + G::kColStride) = lo1;
-            *reinterpret_cast<double*>(wr + G::kPlaneBytes) = hi0;
-            *reinterpret_cast<double*>(wr + G::kPlaneBytes + G::kColStride) = hi1;
+            char* wr = lds_raw + PH * kNIR * ES + row_wr;
+            *reinterpret_cast<T*>(wr) = lo0;
+            *reinterpret_cast<T*>(wr + G::kColStride) = lo1;
+            *reinterpret_cast<T*>(wr + G::kPlaneBytes) = hi0;
+            *reinterpret_cast<T*>(wr + G::kPlaneBytes + G::kColStride) = hi1;
             if constexpr (PH == 0) {
                 if (w == 0) {  // ring rows 0, 1 again behind row kRing-1
-                    *reinterpret_cast<double*>(wr + kRing * 8) = lo0;
-                    *reinterpret_cast<double*>(wr + kRing * 8 + G::kColStride) = lo1;
-                    *reinterpret_cast<double*>(wr + kRing * 8 + G::kPlaneBytes) = hi0;
-                    *reinterpret_cast<double*>(wr + kRing * 8 + G::kPlaneBytes + G::kColStride) = hi1;
+                    *reinterpret_cast<T*>(wr + kRing * ES) = lo0;
+                    *reinterpret_cast<T*>(wr + kRing * ES + G::kColStride) = lo1;
+                    *reinterpret_cast<T*>(wr + kRing * ES + G::kPlaneBytes) = hi0;
+                    *reinterpret_cast<T*>(wr + kRing * ES + G::kPlaneBytes + G::kColStride) = hi1;
                 }
             }
         }
@@ -343,10 +355,10 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable /*read through
 // taps at either end.  out[i] = sum_j x[2i - C + j] F[hlen-1-j] with C = hlen/2 - 1 becomes the same sum over the padded window
 // (C' = C + q, the original taps at positions q .. q+hlen-1); the extra terms are fma(x, 0, acc) = acc, so the result is the one
 // of the unpadded filter bit for bit (finite data).
-template <int HLEN>
-static int launch_fwd_f64lds(const double* in, double* cA, double* cH, double* cV, double* cD, int nr, int nc, int hlen, const Taps2<double>& f)
+template <typename T, int HLEN>
+static int launch_fwd_f64lds(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, int nc, int hlen, const Taps2<T>& f)
 {
-    using G = F64Lds<HLEN>;
+    using G = F64Lds<T, HLEN>;
     const int nr2 = nr / 2, nc2 = nc / 2;
     const int strips = idiv_up(nc2, kNCW);
     // two workgroups per CU when the level is large; one (steps run ~1.7x faster alone) when a chunk is mostly warm-up anyway
@@ -361,21 +373,21 @@ static int launch_fwd_f64lds(const double* in, double* cA, double* cH, double* c
         PDWT_HIP_TRY(hipGetDevice(&dev));
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(done.load(std::memory_order_relaxed) & bit)) {
-            PDWT_HIP_TRY(hipFuncSetAttribute((const void*)k_fwd2d_f64lds<HLEN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
+            PDWT_HIP_TRY(hipFuncSetAttribute((const void*)k_fwd2d_f64lds<T, HLEN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
             done.fetch_or(bit, std::memory_order_relaxed);
         }
     }
-    TapTable tt;  // window position j meets { L[hlen-1-j], H[hlen-1-j] } (SURVEY A-1: out[i] = sum_j x[2i-c+j] F[hlen-1-j])
+    TapTable<T> tt;  // window position j meets { L[hlen-1-j], H[hlen-1-j] } (SURVEY A-1: out[i] = sum_j x[2i-c+j] F[hlen-1-j])
     const int q = (HLEN - hlen) / 2;
     for (int j = 0; j < HLEN; j++) {
         const int k = j - q;
         const bool in_bank = k >= 0 && k < hlen;
-        tt.t[2 * j] = in_bank ? f.a[hlen - 1 - k] : 0.0;
-        tt.t[2 * j + 1] = in_bank ? f.b[hlen - 1 - k] : 0.0;
+        tt.t[2 * j] = in_bank ? f.a[hlen - 1 - k] : T(0);
+        tt.t[2 * j + 1] = in_bank ? f.b[hlen - 1 - k] : T(0);
     }
     KTimer kt(K_FWD2D_F64);
     constexpr size_t lds = G::kLdsBytes;
-    hipLaunchKernelGGL((k_fwd2d_f64lds<HLEN>), dim3(strips * chunks), dim3(kNT), lds, stream(), tt, in, cA, cH, cV, cD, nr, nc, RO, strips);
+    hipLaunchKernelGGL((k_fwd2d_f64lds<T, HLEN>), dim3(strips * chunks), dim3(kNT), lds, stream(), tt, in, cA, cH, cV, cD, nr, nc, RO, strips);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -383,21 +395,35 @@ static int launch_fwd_f64lds(const double* in, double* cA, double* cH, double* c
 // every EVEN filter length up to 40 runs the next instantiated length (zero-padded, see launch_fwd_f64lds)
 static int f64lds_padded_len(int hlen) { return (hlen >= 2 && hlen <= 40 && !(hlen & 1)) ? (hlen + 7) / 8 * 8 : 0; }
 
-int fwd2d_f64_lds(const double* in, double* cA, double* cH, double* cV, double* cD, double* taps_dev, int nr, int nc, int hlen,
-                  const Taps2<double>& f)
+template <typename T>
+static int fwd2d_lds_any(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, int nc, int hlen, const Taps2<T>& f)
 {
     const int hp = f64lds_padded_len(hlen);
     if (knob(KN_F64_LDS) < 1 || !hp || (hp != hlen && knob(KN_F64_LDS) == 3)) return 1;  // (3: exact lengths only)
-    (void)taps_dev;
     if ((nr & 1) || (nc & 1) || nr < 2 * kNIR || nr < hp || nc < hp) return 1;
     if ((long long)nr * nc < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
     switch (hp) {
 #define X(H) \
-    case H: return launch_fwd_f64lds<H>(in, cA, cH, cV, cD, nr, nc, hlen, f);
+    case H: return launch_fwd_f64lds<T, H>(in, cA, cH, cV, cD, nr, nc, hlen, f);
         PDWT_F64LDS_HLENS(X)
 #undef X
         default: return 1;
     }
+}
+
+int fwd2d_f64_lds(const double* in, double* cA, double* cH, double* cV, double* cD, double* taps_dev, int nr, int nc, int hlen,
+                  const Taps2<double>& f)
+{
+    (void)taps_dev;
+    return fwd2d_lds_any<double>(in, cA, cH, cV, cD, nr, nc, hlen, f);
+}
+
+// float32: the cascade / streaming kernels own the banks of up to 16 taps (they are traffic-bound there); longer banks ran the
+// two-pass kernels (2.67x the traffic) and were SLOWER than their double-precision counterparts once those had moved here
+int fwd2d_f32_lds(const float* in, float* cA, float* cH, float* cV, float* cD, int nr, int nc, int hlen, const Taps2<float>& f)
+{
+    if (hlen <= 16 && knob(KN_F64_LDS) != 2) return 1;  // (2: also the short banks, for comparison)
+    return fwd2d_lds_any<float>(in, cA, cH, cV, cD, nr, nc, hlen, f);
 }
 
 // =================================================================================================
@@ -428,28 +454,31 @@ constexpr int kISB = 4;     // steps per unrolled body (ring slots are compile-t
 // NT threads per workgroup: NT/2 per band pair = coefficient columns whose t values the workgroup computes; H2-1 of them are halo.
 // NT = 256: 108 columns produced at db20 (17.6 % of the column synthesis is halo), two workgroups per CU.  (NT = 512 -- 236 columns,
 // 8 % halo, one workgroup per CU -- measured the same time and is not instantiated.)
-template <int HLEN, int NT>
+template <typename T, int HLEN, int NT>
 struct F64Inv {
+    static constexpr int ES = sizeof(T);
     static constexpr int H2 = HLEN / 2, C = H2 / 2, SHIFT = (H2 & 1) ? 0 : 1;
     static constexpr int NCOL = NT / 2;
     static constexpr int INCW = (NCOL - (H2 - 1)) & ~1;  // coefficient columns a workgroup produces outputs for
     static constexpr int NPAIR = INCW / 2;
     static constexpr int WPP = NT / 128;                 // waves per window position in the row synthesis
     static constexpr int PPW = (NPAIR + WPP - 1) / WPP;  // column pairs per wave (<= 32)
-    static constexpr int TSLOTS = NCOL + 1;              // 16-byte slots per row of the t buffer (odd: bank spreading)
-    static constexpr int kTRowBytes = TSLOTS * 16;
+    static constexpr int TSLOTS = NCOL + 1;              // (t1, t2) slots per row of the t buffer (odd: bank spreading)
+    static constexpr int kTRowBytes = TSLOTS * 2 * ES;
     static constexpr int kTBufBytes = 4 * kTRowBytes;
     static constexpr int kLdsBytes = 2 * kTBufBytes;
     static constexpr int RS = H2 - 1 + 2 * kISB;         // ring slots
     static_assert(PPW <= 32 && H2 % 4 == 0 && TSLOTS % 2 == 1, "geometry");
 };
 
-template <int HLEN, int NT>
-__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable /*read through kernarg_taps()*/, const double* __restrict__ cA,
-                                                          const double* __restrict__ cH, const double* __restrict__ cV,
-                                                          const double* __restrict__ cD, double* __restrict__ out, int Nri, int Nci, int NP, int strips)
+template <typename T, int HLEN, int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable<T> /*read through kernarg_taps()*/, const T* __restrict__ cA,
+                                                          const T* __restrict__ cH, const T* __restrict__ cV,
+                                                          const T* __restrict__ cD, T* __restrict__ out, int Nri, int Nci, int NP, int strips)
 {
-    using G = F64Inv<HLEN, NT>;
+    using G = F64Inv<T, HLEN, NT>;
+    using V2 = pair_t<T>;
+    constexpr int ES = sizeof(T);
     constexpr int H2 = G::H2, C = G::C, SHIFT = G::SHIFT, RS = G::RS, kINCW = G::INCW;
     constexpr int NSEC = H2 / 4;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -466,17 +495,17 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
     // ---- column-synthesis role: waves 0,1 -> (A, H), waves 2,3 -> (V, D); thread -> coefficient column c0 - C + lc
     const int pair = w / (NT / 128);
     const int lc = tid & (NT / 2 - 1);
-    const double* const bL = pair ? cV : cA;
-    const double* const bH = pair ? cD : cH;
-    const unsigned ucc = 8u * (unsigned)wrapi(c0 - C + lc, Nci);  // byte offset within a band row
-    const int t_wr = lc * 16 + pair * 8;
+    const T* const bL = pair ? cV : cA;
+    const T* const bH = pair ? cD : cH;
+    const unsigned ucc = (unsigned)ES * (unsigned)wrapi(c0 - C + lc, Nci);  // byte offset within a band row
+    const int t_wr = lc * 2 * ES + pair * ES;
     // chunk-local coefficient row k <-> band row p0 - C + k; rows past the last one the chunk needs are clamped (never consumed)
     const int klast = 2 * nsteps - 1 + H2 - 1;
     // (single conditional wrap: -C <= p0 - C + k < Nri + H2 + 2*kISB, and the dispatcher only sends levels with Nri >= 2*H2 here)
     auto grow = [&](int k) { return (size_t)wrap1(p0 - C + min(k, klast), Nri) * Nci; };
-    double r1[RS], r2[RS];
+    T r1[RS], r2[RS];
 #pragma unroll
-    for (int k = 0; k < RS; k++) r1[k] = r2[k] = 0.0;
+    for (int k = 0; k < RS; k++) r1[k] = r2[k] = T(0);
 #pragma unroll
     for (int k = 0; k < H2 - 1; k++) {
         const size_t o = grow(k);
@@ -498,18 +527,18 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
     const int cp = (((lane >> 5) & 1) << 4) | (((lane >> 2) & 1) << 3) | (((lane >> 4) & 1) << 2) | (lane & 3);
     const bool row_thread = cp < G::PPW && G::PPW * ch + cp < G::NPAIR;
     const int q = row_thread ? G::PPW * ch + cp : 0;         // column pair: coefficient columns c0 + 2q, c0 + 2q + 1
-    const int t_rd = (2 * rg + rbit) * G::kTRowBytes + q * 32;  // window of column c0+2q starts at t slot 2q
+    const int t_rd = (2 * rg + rbit) * G::kTRowBytes + q * 4 * ES;  // window of column c0+2q starts at t slot 2q
     const int co = c0 + 2 * q;
     unsigned uq[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) uq[k] = 8u * (unsigned)wrapi(2 * co - SHIFT + k, Nco);  // byte offsets within an output row
+    for (int k = 0; k < 4; k++) uq[k] = (unsigned)ES * (unsigned)wrapi(2 * co - SHIFT + k, Nco);  // byte offsets within an output row
     unsigned uqr[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) uqr[k] = uq[k] + (rbit ? 8u * (unsigned)Nco : 0u);
+    for (int k = 0; k < 4; k++) uqr[k] = uq[k] + (rbit ? (unsigned)ES * (unsigned)Nco : 0u);
     const bool okA = row_thread && co < Nci, okB = row_thread && co + 1 < Nci;
 
-    ctaps_t tbase = kernarg_taps();
-    double tp1l[2][4], tp0l[2][4], tp1h[2][4], tp0h[2][4];  // taps of the current / next section: IL parity 1, 0; IH parity 1, 0
+    ctaps_t<T> tbase = kernarg_taps<T>();
+    T tp1l[2][4], tp0l[2][4], tp1h[2][4], tp0h[2][4];  // taps of the current / next section: IL parity 1, 0; IH parity 1, 0
 #pragma unroll
     for (int jj = 0; jj < 4; jj++) {
         tp1l[0][jj] = tbase[4 * jj];
@@ -521,12 +550,12 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
     auto step = [&](auto UU, int s) {
         constexpr int U = decltype(UU)::value;  // step within the body: window positions 2U, 2U+1 of the body = ring slots 2U+pos+j
         const char* trow = lds_raw + ((s + 1) & 1) * G::kTBufBytes + t_rd;  // the previous step's rows
-        double cs1[2], cg1[2], cs0[2], cg0[2];  // column synthesis [position]: IL/IH branch, parity 1/0
-        double x1l[2], x1h[2], x0l[2], x0h[2];  // row synthesis [column of the pair]
-        dbl2 P[H2 + 1];                         // (t1, t2) at window slots 0 .. H2 of the pair
+        T cs1[2], cg1[2], cs0[2], cg0[2];  // column synthesis [position]: IL/IH branch, parity 1/0
+        T x1l[2], x1h[2], x0l[2], x0h[2];  // row synthesis [column of the pair]
+        V2 P[H2 + 1];                         // (t1, t2) at window slots 0 .. H2 of the pair
         auto ldP = [&](auto MM) {
             constexpr int m = decltype(MM)::value;
-            P[m] = *reinterpret_cast<const dbl2*>(trow + m * 16);
+            P[m] = *reinterpret_cast<const V2*>(trow + m * 2 * ES);
         };
         static_for<5>([&](auto MM) { ldP(MM); });
         static_for<NSEC>([&](auto SS) {
@@ -534,7 +563,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
             constexpr int gsec = U * NSEC + sec;
             constexpr int cur = gsec & 1, nxt = cur ^ 1;
             constexpr int nsec = (sec + 1) % NSEC;
-            ctaps_t tp = tbase;
+            ctaps_t<T> tp = tbase;
             if constexpr (sec == 0)
                 asm volatile("" : "+s"(tp), "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]), "+v"(P[4]), "+s"(tp1l[cur][0]), "+s"(tp0h[cur][3]));
             else
@@ -567,26 +596,26 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
                         cs0[pos] = r1[slot] * tp0l[cur][jj];
                         cg0[pos] = r2[slot] * tp0h[cur][jj];
                     } else {
-                        cs1[pos] = __builtin_fma(r1[slot], tp1l[cur][jj], cs1[pos]);
-                        cg1[pos] = __builtin_fma(r2[slot], tp1h[cur][jj], cg1[pos]);
-                        cs0[pos] = __builtin_fma(r1[slot], tp0l[cur][jj], cs0[pos]);
-                        cg0[pos] = __builtin_fma(r2[slot], tp0h[cur][jj], cg0[pos]);
+                        cs1[pos] = fma_t<T>(r1[slot], tp1l[cur][jj], cs1[pos]);
+                        cg1[pos] = fma_t<T>(r2[slot], tp1h[cur][jj], cg1[pos]);
+                        cs0[pos] = fma_t<T>(r1[slot], tp0l[cur][jj], cs0[pos]);
+                        cg0[pos] = fma_t<T>(r2[slot], tp0h[cur][jj], cg0[pos]);
                     }
                 });
                 // row synthesis of the previous step's rows: the pair's columns read window slots j and j+1
                 static_for<2>([&](auto KK) {
                     constexpr int k = decltype(KK)::value;
-                    const dbl2 t = P[j + k];
+                    const V2 t = P[j + k];
                     if constexpr (j == 0) {
                         x1l[k] = t.x * tp1l[cur][jj];
                         x1h[k] = t.y * tp1h[cur][jj];
                         x0l[k] = t.x * tp0l[cur][jj];
                         x0h[k] = t.y * tp0h[cur][jj];
                     } else {
-                        x1l[k] = __builtin_fma(t.x, tp1l[cur][jj], x1l[k]);
-                        x1h[k] = __builtin_fma(t.y, tp1h[cur][jj], x1h[k]);
-                        x0l[k] = __builtin_fma(t.x, tp0l[cur][jj], x0l[k]);
-                        x0h[k] = __builtin_fma(t.y, tp0h[cur][jj], x0h[k]);
+                        x1l[k] = fma_t<T>(t.x, tp1l[cur][jj], x1l[k]);
+                        x1h[k] = fma_t<T>(t.y, tp1h[cur][jj], x1h[k]);
+                        x0l[k] = fma_t<T>(t.x, tp0l[cur][jj], x0l[k]);
+                        x0h[k] = fma_t<T>(t.y, tp0h[cur][jj], x0h[k]);
                     }
                 });
             });
@@ -594,19 +623,19 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
         // this step's four rows of t: [position 0: parity 1, parity 0][position 1: parity 1, parity 0]
         {
             char* tw = lds_raw + (s & 1) * G::kTBufBytes + t_wr;
-            *reinterpret_cast<double*>(tw) = cs1[0] + cg1[0];
-            *reinterpret_cast<double*>(tw + G::kTRowBytes) = cs0[0] + cg0[0];
-            *reinterpret_cast<double*>(tw + 2 * G::kTRowBytes) = cs1[1] + cg1[1];
-            *reinterpret_cast<double*>(tw + 3 * G::kTRowBytes) = cs0[1] + cg0[1];
+            *reinterpret_cast<T*>(tw) = cs1[0] + cg1[0];
+            *reinterpret_cast<T*>(tw + G::kTRowBytes) = cs0[0] + cg0[0];
+            *reinterpret_cast<T*>(tw + 2 * G::kTRowBytes) = cs1[1] + cg1[1];
+            *reinterpret_cast<T*>(tw + 3 * G::kTRowBytes) = cs0[1] + cg0[1];
         }
         // outputs of the previous step: window position p -> output rows 2p-SHIFT (+rbit); coefficient columns co, co+1 -> 4 columns
         if (s >= 1) {
             const int pl = 2 * (s - 1) + rg;  // chunk-local window position
             if (pl < np) {
                 const int row0 = wrap1(2 * (p0 + pl) - SHIFT, Nro);  // parity-1 row; the parity-0 row is the next one (periodic)
-                const double o1a = x1l[0] + x1h[0], o0a = x0l[0] + x0h[0], o1b = x1l[1] + x1h[1], o0b = x0l[1] + x0h[1];
+                const T o1a = x1l[0] + x1h[0], o0a = x0l[0] + x0h[0], o1b = x1l[1] + x1h[1], o0b = x0l[1] + x0h[1];
                 if (row0 + 1 < Nro) {  // uniform base + per-lane offset (the lane's row is part of the offset)
-                    double* orow = out + (size_t)row0 * Nco;
+                    T* orow = out + (size_t)row0 * Nco;
                     if (okA) {
                         st_sv(orow, uqr[0], o1a);
                         st_sv(orow, uqr[1], o0a);
@@ -616,19 +645,14 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
                         st_sv(orow, uqr[3], o0b);
                     }
                 } else {  // rows Nro-1 and 0
-                    double* orow = out + (rbit ? (size_t)0 : (size_t)row0 * Nco);
-                    double* q;
+                    T* orow = out + (rbit ? (size_t)0 : (size_t)row0 * Nco);
                     if (okA) {
-                        q = orow + (uq[0] >> 3);
-                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q), "v"(o1a) : "memory");
-                        q = orow + (uq[1] >> 3);
-                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q), "v"(o0a) : "memory");
+                        st_flat(orow + uq[0] / ES, o1a);
+                        st_flat(orow + uq[1] / ES, o0a);
                     }
                     if (okB) {
-                        q = orow + (uq[2] >> 3);
-                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q), "v"(o1b) : "memory");
-                        q = orow + (uq[3] >> 3);
-                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(q), "v"(o0b) : "memory");
+                        st_flat(orow + uq[2] / ES, o1b);
+                        st_flat(orow + uq[3] / ES, o0b);
                     }
                 }
             }
@@ -664,21 +688,20 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
 
 // (zero-padded like the forward bank: out[n] = sum_k c[k] IL[n - 2k + hlen/2 - 1], so q = (HLEN-hlen)/2 zeros in FRONT of the bank
 // keep every product where it was)
-template <int HLEN>
-static int launch_inv_f64lds(const double* cA, const double* cH, const double* cV, const double* cD, double* out, int nri, int nci, int hlen,
-                             const Taps2<double>& f)
+template <typename T, int HLEN>
+static int launch_inv_f64lds(const T* cA, const T* cH, const T* cV, const T* cD, T* out, int nri, int nci, int hlen, const Taps2<T>& f)
 {
     const int nro = 2 * nri, nco = 2 * nci;
     const bool big = (long long)nro * nco >= 2048LL * 2048;
-    const int strips = idiv_up(nci, F64Inv<HLEN, 256>::INCW);
+    const int strips = idiv_up(nci, F64Inv<T, HLEN, 256>::INCW);
     const int target = big ? knob(KN_F64_LDS_WGS) : knob(KN_F64_LDS_WGS) / 2;
     int chunks = std::max(1, target / strips);
     int NP = idiv_up(idiv_up(nri, chunks), 2) * 2;
     NP = std::max(NP, 2 * knob(KN_F64_LDS_MINGROUPS));
     chunks = idiv_up(nri, NP);
-    TapTable tt;  // window position j meets { IL[h-2-2j], IL[h-1-2j], IH[h-2-2j], IH[h-1-2j] } (parity 1 / parity 0)
+    TapTable<T> tt;  // window position j meets { IL[h-2-2j], IL[h-1-2j], IH[h-2-2j], IH[h-1-2j] } (parity 1 / parity 0)
     const int q = (HLEN - hlen) / 2;
-    auto pad = [&](const double* bank, int t) { return (t - q >= 0 && t - q < hlen) ? bank[t - q] : 0.0; };
+    auto pad = [&](const T* bank, int t) { return (t - q >= 0 && t - q < hlen) ? bank[t - q] : T(0); };
     for (int j = 0; j < HLEN / 2; j++) {
         tt.t[4 * j + 0] = pad(f.a, HLEN - 2 - 2 * j);
         tt.t[4 * j + 1] = pad(f.a, HLEN - 1 - 2 * j);
@@ -686,27 +709,41 @@ static int launch_inv_f64lds(const double* cA, const double* cH, const double* c
         tt.t[4 * j + 3] = pad(f.b, HLEN - 1 - 2 * j);
     }
     KTimer kt(K_INV2D_F64);
-    constexpr size_t lds256 = F64Inv<HLEN, 256>::kLdsBytes;
-    hipLaunchKernelGGL((k_inv2d_f64lds<HLEN, 256>), dim3(strips * chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP, strips);
+    constexpr size_t lds256 = F64Inv<T, HLEN, 256>::kLdsBytes;
+    hipLaunchKernelGGL((k_inv2d_f64lds<T, HLEN, 256>), dim3(strips * chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP, strips);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
+}
+
+template <typename T>
+static int inv2d_lds_any(const T* cA, const T* cH, const T* cV, const T* cD, T* out, int nri, int nci, int nro, int nco, int hlen,
+                         const Taps2<T>& f)
+{
+    const int hp = f64lds_padded_len(hlen);
+    if (knob(KN_F64_LDS) < 1 || !hp || (hp != hlen && knob(KN_F64_LDS) == 3)) return 1;
+    if (nro != 2 * nri || nco != 2 * nci || nri < hp || nci < 2) return 1;  // (row indices wrap at most once: wrap1)
+    if ((long long)nro * nco < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
+    switch (hp) {
+#define X(H) \
+    case H: return launch_inv_f64lds<T, H>(cA, cH, cV, cD, out, nri, nci, hlen, f);
+        PDWT_F64LDS_HLENS(X)
+#undef X
+        default: return 1;
+    }
 }
 
 int inv2d_f64_lds(const double* cA, const double* cH, const double* cV, const double* cD, double* out, double* taps_dev, int nri, int nci,
                   int nro, int nco, int hlen, const Taps2<double>& f)
 {
-    const int hp = f64lds_padded_len(hlen);
-    if (knob(KN_F64_LDS) < 1 || !hp || (hp != hlen && knob(KN_F64_LDS) == 3)) return 1;
     (void)taps_dev;
-    if (nro != 2 * nri || nco != 2 * nci || nri < hp || nci < 2) return 1;  // (row indices wrap at most once: wrap1)
-    if ((long long)nro * nco < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
-    switch (hp) {
-#define X(H) \
-    case H: return launch_inv_f64lds<H>(cA, cH, cV, cD, out, nri, nci, hlen, f);
-        PDWT_F64LDS_HLENS(X)
-#undef X
-        default: return 1;
-    }
+    return inv2d_lds_any<double>(cA, cH, cV, cD, out, nri, nci, nro, nco, hlen, f);
+}
+
+int inv2d_f32_lds(const float* cA, const float* cH, const float* cV, const float* cD, float* out, int nri, int nci, int nro, int nco,
+                  int hlen, const Taps2<float>& f)
+{
+    if (hlen <= 16 && knob(KN_F64_LDS) != 2) return 1;
+    return inv2d_lds_any<float>(cA, cH, cV, cD, out, nri, nci, nro, nco, hlen, f);
 }
 
 }  // namespace pdwt

@@ -769,7 +769,7 @@ def test_stress_cascade_random_shapes():
 
 
 def test_f64_long_filter_level_kernels_random_shapes():
-    """dwt_f64_lds.hip (db20 / float64: both passes of a level in one launch, rings in LDS / split register rings) is the same
+    """dwt_lds.hip (db20 / float64: both passes of a level in one launch, rings in LDS / split register rings) is the same
     arithmetic as the two-pass kernels, bit for bit, over random even shapes (strips that do not divide the width, chunks
     shorter than the ring warm-up, depths down to 2x-the-filter levels), and as the older fused form where that one applies;
     one geometry is also checked against the oracle."""
@@ -835,6 +835,31 @@ def test_f64_long_filter_level_kernels_random_shapes():
         W.inverse()
         O.inverse()
         assert band_err(W.get_image(), O.get_image()) <= 1e-10
+
+
+def test_f32_long_filter_level_kernels():
+    """float32 banks of more than 16 taps run the LDS-ring level kernels too (dwt_lds.hip): bit-identical to the two-pass kernels
+    they replace and within 1e-5 of the oracle."""
+    rs = np.random.RandomState(78)
+    for wname in ("db9", "db10", "db12", "db16", "db20", "sym13", "coif3", "coif5", "bior6.8"):
+        nr, nc, lev = 2 * rs.randint(140, 700), 2 * rs.randint(140, 700), rs.randint(1, 4)
+        x = rs.uniform(0, 255, (nr, nc)).astype(np.float32)
+        res = []
+        for kn in (dict(), dict(f64_lds=0)):
+            with knobs(f64_lds_min=0, **kn):
+                W = pdwt_amd.Wavelets(x, wname, lev)
+                W.forward()
+                c = W.coeffs
+                W.inverse()
+                res.append((c, W.get_image()))
+        for k, (a, b) in enumerate(zip(res[0][0], res[1][0])):
+            assert np.array_equal(a, b), (wname, nr, nc, lev, "band", k)
+        assert np.array_equal(res[0][1], res[1][1]), (wname, nr, nc, lev)
+        O = orc.OracleWavelets(x, wname, lev)
+        O.forward()
+        for g, o in zip(res[0][0], O.coeffs):
+            assert band_err(g, o) <= 1e-5, wname
+        assert band_err(res[0][1], x) <= 1e-5, wname
 
 
 def test_norm2sq_is_the_squared_l2_norm_in_1d():

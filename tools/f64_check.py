@@ -11,6 +11,7 @@ L = pdwt_amd.hip()
 lev = int(sys.argv[1])
 import os
 WN = os.environ.get("WNAME", "db20")
+DT = torch.float32 if os.environ.get("DTYPE", "f64") == "f32" else torch.float64
 
 
 def run(x, lev, **kn):
@@ -35,7 +36,7 @@ def run(x, lev, **kn):
 for a in sys.argv[2:]:
     nr, nc = (int(v) for v in a.split("x")) if "x" in a else (int(a), int(a))
     torch.manual_seed(nr * 7 + nc)
-    x = torch.rand((nr, nc), device="cuda", dtype=torch.float64) - 0.5
+    x = torch.rand((nr, nc), device="cuda", dtype=DT) - 0.5
     c1, i1 = run(x, lev)
     c0, i0 = run(x, lev, force_twopass=1)
     bad = [k for k in range(len(c0)) if not torch.equal(c0[k], c1[k])]
