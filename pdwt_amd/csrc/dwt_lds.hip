@@ -79,6 +79,30 @@ __device__ __forceinline__ void st_sv(float* base, unsigned boff, float v)
 {
     asm volatile("global_store_dword %0, %1, %2" ::"v"(boff), "v"(v), "s"(base) : "memory");
 }
+// (a0, a1) (+)= x * (t0, t1): two accumulators fed by one sample and an adjacent pair of taps.  float: ONE v_pk_fma_f32 (the sample is
+// broadcast by op_sel, the taps are an aligned SGPR pair); each half is the same single FMA as in the scalar form.
+__device__ __forceinline__ void fma2(double& a0, double& a1, double x, double t0, double t1)
+{
+    a0 = __builtin_fma(x, t0, a0);
+    a1 = __builtin_fma(x, t1, a1);
+}
+__device__ __forceinline__ void mul2(double& a0, double& a1, double x, double t0, double t1)
+{
+    a0 = x * t0;
+    a1 = x * t1;
+}
+__device__ __forceinline__ void fma2(float& a0, float& a1, float x, float t0, float t1)
+{
+    const v2f r = pk_fma(v2f{x, x}, v2f{t0, t1}, v2f{a0, a1});
+    a0 = r.x;
+    a1 = r.y;
+}
+__device__ __forceinline__ void mul2(float& a0, float& a1, float x, float t0, float t1)
+{
+    const v2f r = v2f{x, x} * v2f{t0, t1};
+    a0 = r.x;
+    a1 = r.y;
+}
 __device__ __forceinline__ void st_flat(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void st_flat(float* p, float v) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 }  // namespace
@@ -252,20 +276,14 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read thro
                 constexpr int jj = 2 * m;
                 const V2 p = P[4 * sec + m], q = P[4 * sec + m + 1];
                 if constexpr (sec == 0 && m == 0) {  // fma(x, t, 0) == x * t: no zero-initialisation moves
-                    lo0 = p.x * tl[cur][jj];
-                    hi0 = p.x * th[cur][jj];
-                    lo1 = q.x * tl[cur][jj];
-                    hi1 = q.x * th[cur][jj];
+                    mul2(lo0, hi0, p.x, tl[cur][jj], th[cur][jj]);
+                    mul2(lo1, hi1, q.x, tl[cur][jj], th[cur][jj]);
                 } else {
-                    lo0 = fma_t<T>(p.x, tl[cur][jj], lo0);
-                    hi0 = fma_t<T>(p.x, th[cur][jj], hi0);
-                    lo1 = fma_t<T>(q.x, tl[cur][jj], lo1);
-                    hi1 = fma_t<T>(q.x, th[cur][jj], hi1);
+                    fma2(lo0, hi0, p.x, tl[cur][jj], th[cur][jj]);
+                    fma2(lo1, hi1, q.x, tl[cur][jj], th[cur][jj]);
                 }
-                lo0 = fma_t<T>(p.y, tl[cur][jj + 1], lo0);
-                hi0 = fma_t<T>(p.y, th[cur][jj + 1], hi0);
-                lo1 = fma_t<T>(q.y, tl[cur][jj + 1], lo1);
-                hi1 = fma_t<T>(q.y, th[cur][jj + 1], hi1);
+                fma2(lo0, hi0, p.y, tl[cur][jj + 1], th[cur][jj + 1]);
+                fma2(lo1, hi1, q.y, tl[cur][jj + 1], th[cur][jj + 1]);
             });
             // column pass: output rows 4g+rp and 4g+rp+2 (g = s-kLag); ring rows rho = 8g + 2 + 2rp + k, tap j meets k = j (first
             // row) and k = j+4 (second row).  (During the first kLag steps of a chunk this works on rows that do not exist yet; nothing
@@ -275,20 +293,14 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read thro
                 constexpr int jj = 2 * m;
                 const V2 p = Q[4 * sec + m], q = Q[4 * sec + m + 2];
                 if constexpr (sec == 0 && m == 0) {
-                    a0 = p.x * tl[cur][jj];
-                    h0 = p.x * th[cur][jj];
-                    a1 = q.x * tl[cur][jj];
-                    h1 = q.x * th[cur][jj];
+                    mul2(a0, h0, p.x, tl[cur][jj], th[cur][jj]);
+                    mul2(a1, h1, q.x, tl[cur][jj], th[cur][jj]);
                 } else {
-                    a0 = fma_t<T>(p.x, tl[cur][jj], a0);
-                    h0 = fma_t<T>(p.x, th[cur][jj], h0);
-                    a1 = fma_t<T>(q.x, tl[cur][jj], a1);
-                    h1 = fma_t<T>(q.x, th[cur][jj], h1);
+                    fma2(a0, h0, p.x, tl[cur][jj], th[cur][jj]);
+                    fma2(a1, h1, q.x, tl[cur][jj], th[cur][jj]);
                 }
-                a0 = fma_t<T>(p.y, tl[cur][jj + 1], a0);
-                h0 = fma_t<T>(p.y, th[cur][jj + 1], h0);
-                a1 = fma_t<T>(q.y, tl[cur][jj + 1], a1);
-                h1 = fma_t<T>(q.y, th[cur][jj + 1], h1);
+                fma2(a0, h0, p.y, tl[cur][jj + 1], th[cur][jj + 1]);
+                fma2(a1, h1, q.y, tl[cur][jj + 1], th[cur][jj + 1]);
             });
         });
         // new ring rows 8*PH + rrow (ring planes are stored column-major: the column pass reads two rows per 16 bytes)
@@ -591,15 +603,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
                     constexpr int pos = decltype(PP)::value;
                     constexpr int slot = 2 * U + pos + j;
                     if constexpr (j == 0) {  // fma(x, t, 0) == x * t: no zero-initialisation moves
-                        cs1[pos] = r1[slot] * tp1l[cur][jj];
-                        cg1[pos] = r2[slot] * tp1h[cur][jj];
-                        cs0[pos] = r1[slot] * tp0l[cur][jj];
-                        cg0[pos] = r2[slot] * tp0h[cur][jj];
+                        mul2(cs1[pos], cs0[pos], r1[slot], tp1l[cur][jj], tp0l[cur][jj]);
+                        mul2(cg1[pos], cg0[pos], r2[slot], tp1h[cur][jj], tp0h[cur][jj]);
                     } else {
-                        cs1[pos] = fma_t<T>(r1[slot], tp1l[cur][jj], cs1[pos]);
-                        cg1[pos] = fma_t<T>(r2[slot], tp1h[cur][jj], cg1[pos]);
-                        cs0[pos] = fma_t<T>(r1[slot], tp0l[cur][jj], cs0[pos]);
-                        cg0[pos] = fma_t<T>(r2[slot], tp0h[cur][jj], cg0[pos]);
+                        fma2(cs1[pos], cs0[pos], r1[slot], tp1l[cur][jj], tp0l[cur][jj]);
+                        fma2(cg1[pos], cg0[pos], r2[slot], tp1h[cur][jj], tp0h[cur][jj]);
                     }
                 });
                 // row synthesis of the previous step's rows: the pair's columns read window slots j and j+1
@@ -607,15 +615,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
                     constexpr int k = decltype(KK)::value;
                     const V2 t = P[j + k];
                     if constexpr (j == 0) {
-                        x1l[k] = t.x * tp1l[cur][jj];
-                        x1h[k] = t.y * tp1h[cur][jj];
-                        x0l[k] = t.x * tp0l[cur][jj];
-                        x0h[k] = t.y * tp0h[cur][jj];
+                        mul2(x1l[k], x0l[k], t.x, tp1l[cur][jj], tp0l[cur][jj]);
+                        mul2(x1h[k], x0h[k], t.y, tp1h[cur][jj], tp0h[cur][jj]);
                     } else {
-                        x1l[k] = fma_t<T>(t.x, tp1l[cur][jj], x1l[k]);
-                        x1h[k] = fma_t<T>(t.y, tp1h[cur][jj], x1h[k]);
-                        x0l[k] = fma_t<T>(t.x, tp0l[cur][jj], x0l[k]);
-                        x0h[k] = fma_t<T>(t.y, tp0h[cur][jj], x0h[k]);
+                        fma2(x1l[k], x0l[k], t.x, tp1l[cur][jj], tp0l[cur][jj]);
+                        fma2(x1h[k], x0h[k], t.y, tp1h[cur][jj], tp0h[cur][jj]);
                     }
                 });
             });
