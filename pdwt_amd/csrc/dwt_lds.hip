@@ -136,7 +136,10 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read thro
     constexpr int NSEC = HLEN / 8;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Nc2 = Nc >> 1, Nr2 = Nr >> 1;
+    // odd sizes: the reference's rule (src/separable.cu:116-121) -- repeat the last sample once, then periodic -- is applied while
+    // the rows are staged: Nv x (Nc + (Nc & 1)) is the virtual image, ceil-half the band size
+    const int Nc2 = (Nc + 1) >> 1, Nr2 = (Nr + 1) >> 1;
+    const int Nv = Nr + (Nr & 1);
     int strip, chunk;
     xcd_tile(strips, strip, chunk);
     const int i0 = strip * kNCW;
@@ -152,13 +155,13 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read thro
     unsigned gc[3][2];  // byte offsets within an image row
 #pragma unroll
     for (int m = 0; m < 3; m++) {
-        gc[m][0] = (unsigned)ES * (unsigned)wrapi(cbase + 2 * (k0 + 32 * m), Nc);
-        gc[m][1] = (unsigned)ES * (unsigned)wrapi(cbase + 2 * (k0 + 32 * m) + 1, Nc);
+        gc[m][0] = (unsigned)ES * (unsigned)wrap_ext(cbase + 2 * (k0 + 32 * m), Nc);
+        gc[m][1] = (unsigned)ES * (unsigned)wrap_ext(cbase + 2 * (k0 + 32 * m) + 1, Nc);
     }
     const unsigned rowb = (unsigned)ES * (unsigned)Nc * (unsigned)srow;  // the thread's row within the 8 rows of a step (when they do not wrap)
     const bool third = k0 + 64 < PAIRS;
     // chunk-local row rho <-> image row 2*y0 - C - 2 + rho (two leading rows align the output groups with the steps)
-    int rnext = wrapi(2 * y0 - C - 2, Nr);  // image row of rho = 8*(step to stage)
+    int rnext = wrapi(2 * y0 - C - 2, Nv);  // (virtual) image row of rho = 8*(step to stage)
     T st[3][2];
     auto load_rows = [&]() {
         if (rnext + kNIR <= Nr) {  // the step's 8 rows are consecutive: uniform base + 32-bit per-lane offset
@@ -173,7 +176,8 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read thro
             }
         } else {  // (uniform; at most two steps of a chunk) they wrap around the bottom edge: per-lane 64-bit row pointers
             const int r = rnext + srow;
-            const char* p = reinterpret_cast<const char*>(in + (size_t)(r >= Nr ? r - Nr : r) * Nc);
+            const int rv = r >= Nv ? r - Nv : r;  // virtual row; row Nr (odd heights) is row Nr-1 again
+            const char* p = reinterpret_cast<const char*>(in + (size_t)min(rv, Nr - 1) * Nc);
             st[0][0] = *reinterpret_cast<const T*>(p + gc[0][0]);
             st[0][1] = *reinterpret_cast<const T*>(p + gc[0][1]);
             st[1][0] = *reinterpret_cast<const T*>(p + gc[1][0]);
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read thro
             }
         }
         rnext += kNIR;
-        rnext = rnext >= Nr ? rnext - Nr : rnext;
+        rnext = rnext >= Nv ? rnext - Nv : rnext;
     };
     char* const in_lds = lds_raw + 2 * G::kPlaneBytes;
     int stage_off = srow * LWI * ES + k0 * 2 * ES;  // within an input buffer
@@ -371,7 +375,7 @@ template <typename T, int HLEN>
 static int launch_fwd_f64lds(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, int nc, int hlen, const Taps2<T>& f)
 {
     using G = F64Lds<T, HLEN>;
-    const int nr2 = nr / 2, nc2 = nc / 2;
+    const int nr2 = div2(nr), nc2 = div2(nc);
     const int strips = idiv_up(nc2, kNCW);
     // two workgroups per CU when the level is large; one (steps run ~1.7x faster alone) when a chunk is mostly warm-up anyway
     const int target = (long long)nr * nc >= 2048LL * 2048 ? knob(KN_F64_LDS_WGS) : knob(KN_F64_LDS_WGS) / 2;
@@ -412,7 +416,7 @@ static int fwd2d_lds_any(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, int nc
 {
     const int hp = f64lds_padded_len(hlen);
     if (knob(KN_F64_LDS) < 1 || !hp || (hp != hlen && knob(KN_F64_LDS) == 3)) return 1;  // (3: exact lengths only)
-    if ((nr & 1) || (nc & 1) || nr < 2 * kNIR || nr < hp || nc < hp) return 1;
+    if (nr < 2 * kNIR || nr < hp || nc < hp) return 1;
     if ((long long)nr * nc < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
     switch (hp) {
 #define X(H) \
@@ -430,11 +434,13 @@ int fwd2d_f64_lds(const double* in, double* cA, double* cH, double* cV, double* 
     return fwd2d_lds_any<double>(in, cA, cH, cV, cD, nr, nc, hlen, f);
 }
 
-// float32: the cascade / streaming kernels own the banks of up to 16 taps (they are traffic-bound there); longer banks ran the
-// two-pass kernels (2.67x the traffic) and were SLOWER than their double-precision counterparts once those had moved here
+// float32: the cascade / streaming kernels own the banks of up to 16 taps on the geometries they take (they are traffic-bound
+// there) and are tried first by the level driver; this is what runs otherwise -- longer banks (they ran the two-pass kernels, 2.67x
+// the traffic, and were SLOWER than their double-precision counterparts once those had moved here) and short banks on odd or
+// not-multiple-of-4 sizes (the LDS-tiled kernel before: 4095x4097 db4 L3 186 -> 116 us per pair, 1001x1003 69 -> 48)
 int fwd2d_f32_lds(const float* in, float* cA, float* cH, float* cV, float* cD, int nr, int nc, int hlen, const Taps2<float>& f)
 {
-    if (hlen <= 16 && knob(KN_F64_LDS) != 2) return 1;  // (2: also the short banks, for comparison)
+    if (hlen <= 16 && knob(KN_F64_LDS) == 4) return 1;  // (4: long banks only, for comparison)
     return fwd2d_lds_any<float>(in, cA, cH, cV, cD, nr, nc, hlen, f);
 }
 
@@ -486,7 +492,7 @@ struct F64Inv {
 template <typename T, int HLEN, int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable<T> /*read through kernarg_taps()*/, const T* __restrict__ cA,
                                                           const T* __restrict__ cH, const T* __restrict__ cV,
-                                                          const T* __restrict__ cD, T* __restrict__ out, int Nri, int Nci, int NP, int strips)
+                                                          const T* __restrict__ cD, T* __restrict__ out, int Nri, int Nci, int Nro, int Nco, int NP, int strips)
 {
     using G = F64Inv<T, HLEN, NT>;
     using V2 = pair_t<T>;
@@ -495,7 +501,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
     constexpr int NSEC = H2 / 4;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Nro = 2 * Nri, Nco = 2 * Nci;
+    // (Nro, Nco): the output size, 2*Nri or 2*Nri - 1 (odd outputs: the synthesis runs on the even size, the last row / column is not stored)
+    const int Nrv = 2 * Nri, Ncv = 2 * Nci;
     int strip, chunk;
     xcd_tile(strips, strip, chunk);
     const int c0 = strip * kINCW;
@@ -543,11 +550,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
     const int co = c0 + 2 * q;
     unsigned uq[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) uq[k] = (unsigned)ES * (unsigned)wrapi(2 * co - SHIFT + k, Nco);  // byte offsets within an output row
+    for (int k = 0; k < 4; k++) uq[k] = (unsigned)ES * (unsigned)wrapi(2 * co - SHIFT + k, Ncv);  // byte offsets within an output row
     unsigned uqr[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) uqr[k] = uq[k] + (rbit ? (unsigned)ES * (unsigned)Nco : 0u);
+    const unsigned colend = (unsigned)ES * (unsigned)Nco;  // (columns >= Nco exist only for odd Nco: the dropped one)
     const bool okA = row_thread && co < Nci, okB = row_thread && co + 1 < Nci;
+    const bool ok0 = okA && uq[0] < colend, ok1 = okA && uq[1] < colend, ok2 = okB && uq[2] < colend, ok3 = okB && uq[3] < colend;
 
     ctaps_t<T> tbase = kernarg_taps<T>();
     T tp1l[2][4], tp0l[2][4], tp1h[2][4], tp0h[2][4];  // taps of the current / next section: IL parity 1, 0; IH parity 1, 0
@@ -636,28 +645,22 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
         if (s >= 1) {
             const int pl = 2 * (s - 1) + rg;  // chunk-local window position
             if (pl < np) {
-                const int row0 = wrap1(2 * (p0 + pl) - SHIFT, Nro);  // parity-1 row; the parity-0 row is the next one (periodic)
+                const int row0 = wrap1(2 * (p0 + pl) - SHIFT, Nrv);  // parity-1 row; the parity-0 row is the next one (periodic)
                 const T o1a = x1l[0] + x1h[0], o0a = x0l[0] + x0h[0], o1b = x1l[1] + x1h[1], o0b = x0l[1] + x0h[1];
-                if (row0 + 1 < Nro) {  // uniform base + per-lane offset (the lane's row is part of the offset)
+                if (row0 + 1 < Nrv) {  // uniform base + per-lane offset (the lane's row is part of the offset)
                     T* orow = out + (size_t)row0 * Nco;
-                    if (okA) {
-                        st_sv(orow, uqr[0], o1a);
-                        st_sv(orow, uqr[1], o0a);
+                    if (row0 + rbit < Nro) {
+                        if (ok0) st_sv(orow, uqr[0], o1a);
+                        if (ok1) st_sv(orow, uqr[1], o0a);
+                        if (ok2) st_sv(orow, uqr[2], o1b);
+                        if (ok3) st_sv(orow, uqr[3], o0b);
                     }
-                    if (okB) {
-                        st_sv(orow, uqr[2], o1b);
-                        st_sv(orow, uqr[3], o0b);
-                    }
-                } else {  // rows Nro-1 and 0
+                } else if (rbit || row0 < Nro) {  // rows Nrv-1 (dropped when the output height is odd) and 0
                     T* orow = out + (rbit ? (size_t)0 : (size_t)row0 * Nco);
-                    if (okA) {
-                        st_flat(orow + uq[0] / ES, o1a);
-                        st_flat(orow + uq[1] / ES, o0a);
-                    }
-                    if (okB) {
-                        st_flat(orow + uq[2] / ES, o1b);
-                        st_flat(orow + uq[3] / ES, o0b);
-                    }
+                    if (ok0) st_flat(orow + uq[0] / ES, o1a);
+                    if (ok1) st_flat(orow + uq[1] / ES, o0a);
+                    if (ok2) st_flat(orow + uq[2] / ES, o1b);
+                    if (ok3) st_flat(orow + uq[3] / ES, o0b);
                 }
             }
         }
@@ -693,9 +696,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
 // (zero-padded like the forward bank: out[n] = sum_k c[k] IL[n - 2k + hlen/2 - 1], so q = (HLEN-hlen)/2 zeros in FRONT of the bank
 // keep every product where it was)
 template <typename T, int HLEN>
-static int launch_inv_f64lds(const T* cA, const T* cH, const T* cV, const T* cD, T* out, int nri, int nci, int hlen, const Taps2<T>& f)
+static int launch_inv_f64lds(const T* cA, const T* cH, const T* cV, const T* cD, T* out, int nri, int nci, int nro, int nco, int hlen,
+                             const Taps2<T>& f)
 {
-    const int nro = 2 * nri, nco = 2 * nci;
     const bool big = (long long)nro * nco >= 2048LL * 2048;
     const int strips = idiv_up(nci, F64Inv<T, HLEN, 256>::INCW);
     const int target = big ? knob(KN_F64_LDS_WGS) : knob(KN_F64_LDS_WGS) / 2;
@@ -714,7 +717,7 @@ static int launch_inv_f64lds(const T* cA, const T* cH, const T* cV, const T* cD,
     }
     KTimer kt(K_INV2D_F64);
     constexpr size_t lds256 = F64Inv<T, HLEN, 256>::kLdsBytes;
-    hipLaunchKernelGGL((k_inv2d_f64lds<T, HLEN, 256>), dim3(strips * chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, NP, strips);
+    hipLaunchKernelGGL((k_inv2d_f64lds<T, HLEN, 256>), dim3(strips * chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, nro, nco, NP, strips);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -725,11 +728,11 @@ static int inv2d_lds_any(const T* cA, const T* cH, const T* cV, const T* cD, T* 
 {
     const int hp = f64lds_padded_len(hlen);
     if (knob(KN_F64_LDS) < 1 || !hp || (hp != hlen && knob(KN_F64_LDS) == 3)) return 1;
-    if (nro != 2 * nri || nco != 2 * nci || nri < hp || nci < 2) return 1;  // (row indices wrap at most once: wrap1)
+    if (nri != div2(nro) || nci != div2(nco) || nri < hp || nci < 2) return 1;  // (row indices wrap at most once: wrap1)
     if ((long long)nro * nco < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
     switch (hp) {
 #define X(H) \
-    case H: return launch_inv_f64lds<T, H>(cA, cH, cV, cD, out, nri, nci, hlen, f);
+    case H: return launch_inv_f64lds<T, H>(cA, cH, cV, cD, out, nri, nci, nro, nco, hlen, f);
         PDWT_F64LDS_HLENS(X)
 #undef X
         default: return 1;
@@ -746,7 +749,7 @@ int inv2d_f64_lds(const double* cA, const double* cH, const double* cV, const do
 int inv2d_f32_lds(const float* cA, const float* cH, const float* cV, const float* cD, float* out, int nri, int nci, int nro, int nco,
                   int hlen, const Taps2<float>& f)
 {
-    if (hlen <= 16 && knob(KN_F64_LDS) != 2) return 1;
+    if (hlen <= 16 && knob(KN_F64_LDS) == 4) return 1;
     return inv2d_lds_any<float>(cA, cH, cV, cD, out, nri, nci, nro, nco, hlen, f);
 }
 
