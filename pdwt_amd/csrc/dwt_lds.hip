@@ -1,6 +1,8 @@
-// dwt_lds.hip -- one 2-D DWT level per launch with both passes fed from LDS: every double-precision bank of even length and the
-// float32 banks of more than 16 taps (written for db20 in double, 40 taps: the C5 configuration; other lengths run the next
-// multiple of 8, zero-padded).
+// dwt_lds.hip -- one 2-D DWT level per launch with both passes fed from LDS, templated over the element type and the bank length.
+// Runs: every double-precision bank of even length; the float32 banks of more than 16 taps; the float32 banks of up to 16 taps on
+// the geometries the cascade / streaming kernels do not take (odd sizes, sizes that are not a multiple of 4).  Written for db20 in
+// double (40 taps: configuration C5) -- the figures in the comments are that case.  Lengths that are not a multiple of 8 run the next
+// one with a symmetrically zero-padded bank; odd sizes follow the reference's repeat-last-sample-then-periodic rule.
 //
 // Reference code replaced: w_kern_forward_pass1 + w_kern_forward_pass2 (src/separable.cu:91-176) of one iteration of
 // w_forward_separable (:179-209).
@@ -10,20 +12,21 @@
 // of the time.  Here the ring lives in LDS and every thread is register-blocked over TWO outputs of the pass it runs:
 //   * a workgroup (256 threads, two per CU) owns 64 output columns and walks down a chunk, 8 input rows (4 output rows) per step;
 //   * ROW pass: thread = (input row, pair of adjacent output columns); its two 40-sample windows overlap in 38 samples, so 21
-//     aligned 16-byte LDS reads feed 160 FMAs; results (lo, hi) go to a ring of 56 rows in LDS (two planes);
-//   * COLUMN pass: thread = (plane, column, output rows q and q+2 of the step's four): 44 8-byte LDS reads feed 160 FMAs, emits
+//     aligned two-sample LDS reads (16 bytes in double) feed 160 FMAs; results (lo, hi) go to a ring of 56 rows in LDS (two planes,
+//     column-major so that one read delivers two ring rows);
+//   * COLUMN pass: thread = (plane, column, output rows q and q+2 of the step's four): 22 two-row reads feed 160 FMAs, emits
 //     (A,H) or (V,D).  The two row pairs of a step differ by two ring rows; that offset sits in the base register, so the
 //     wrap-around of the ring is the same immediate for both and rows 0, 1 are mirrored behind the last ring row;
 //   * 0.13 LDS reads per FMA as before, but ~100 VGPRs of read-ahead instead of none; the column pass of a group of rows runs in the
 //     same step as the row pass of the NEXT rows (one barrier per step), and both passes of a section share the section's taps,
-//     which arrive by scalar loads through a laundered constant-address-space pointer exactly as in dwt_f64_fused.hip.
-//   * Bank conflicts: the 16 lanes an LDS cycle serves start their windows 32 bytes apart (two output columns) -- a 2-way conflict
-//     on 16-byte reads.  A wave therefore works on TWO input rows whose LDS images are an ODD number of 16-byte slots apart
-//     (row = 83 slots), and the lanes are dealt so that every lane group holds eight windows of each row: 16 distinct slots.
+//     which arrive by scalar loads straight from the kernarg segment (the tap table is the first kernel argument);
+//   * Bank conflicts: the lanes an LDS cycle serves start their windows two output columns apart -- a 2-way conflict.  A wave
+//     therefore works on TWO input rows whose LDS images are an ODD number of two-sample slots apart (row = 83 slots at db20), and
+//     the lanes are dealt so that every lane group holds as many windows of one row as of the other: all banks, once.
 //   * The ring position of a step repeats every 7 steps; the body is unrolled over those 7 phases so that every LDS address is
 //     base register + immediate.
 // Per-sample arithmetic: taps in ascending window position, one FMA per tap, rows before columns -- the reference's and the
-// oracle's order: bit-identical to the two-pass kernels.
+// oracle's order: bit-identical to the two-pass kernels (float32: two such FMAs per v_pk_fma_f32).
 #include "dwt_f64_fused.hpp"
 
 #include <algorithm>
