@@ -99,6 +99,7 @@ enum KnobId {
     KN_SWTF_M,             // fused SWT forward: rows per chunk (0 = auto)
     KN_SWTF_MI,            // fused SWT inverse: rows per chunk (0 = auto)
     KN_SWTF_XCD,           // fused SWT levels: XCD-aware tile order
+    KN_SWTF_PERM,          // fused SWT inverse, tap spacing 4/8/16: residue-major LDS rows
     KN_F64_FUSED,
     KN_F64_FUSED_MIN,      // fused long double-precision level kernels: smallest level side (pixels)
     KN_F64_LDS,            // LDS-ring form of the fused long double-precision level kernels (dwt_lds.hip)
