@@ -19,7 +19,7 @@ KMAP = {"k_fwd2d_casc": "fwd2d_casc", "k_inv2d_casc": "inv2d_casc", "k_inv2d_cas
         "k_ana_rows": "ana_rows", "k_ana_rows_tr": "ana_rows", "k_syn_rows_tr": "syn_rows", "k_ana_cols": "ana_cols", "k_syn_rows": "syn_rows", "k_syn_cols": "syn_cols",
         "k_fwd1d_stream": "ana_rows", "k_inv1d_stream": "syn_rows", "k_fwd1d_fused": "ana_rows", "k_inv1d_fused": "syn_rows", "k_inv1d_fused_pf": "syn_rows",
         "k_ana_cols_ring": "ana_cols", "k_ana_cols_ring_tr": "ana_cols", "k_syn_cols_ring": "syn_cols", "k_syn_cols_ring_tr": "syn_cols",
-        "k_swt_fwd_fused": "swt_ana_cols", "k_swt_inv_fused": "swt_syn_cols", "k_swt_inv_fused4": "swt_syn_cols",
+        "k_swt_fwd_fused": "swt_ana_cols", "k_swt_inv_fused": "swt_syn_cols", "k_swt_inv_fused4": "swt_syn_cols", "k_swt_inv_fusedp": "swt_syn_cols",
         "k_swt_ana_rows": "swt_ana_rows", "k_swt_ana_cols": "swt_ana_cols", "k_swt_syn_rows": "swt_syn_rows", "k_swt_syn_cols": "swt_syn_cols"}
 
 
