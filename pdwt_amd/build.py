@@ -64,7 +64,7 @@ def build_hip(force=False):
         if force or extra or _newer([sp] + hdrs, obj):
             jobs.append([hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall"] + extra + ["-c", sp, "-o", obj])
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(max(8, (os.cpu_count() or 8) // 2), len(jobs))) as ex:
             list(ex.map(_run, jobs))
     if jobs or not os.path.exists(out):
         _run([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs)
