@@ -458,7 +458,7 @@ class PowerSampler:
         """Samples with t0 <= timestamp <= t1 -> summary dict (None when there are none)."""
         if not self.proc or not self.path:
             return None
-        clk, pw, temp, limit = [], [], [], None
+        allrec, limit = [], None
         try:
             for ln in open(self.path):
                 if ln.startswith("# limit"):
@@ -470,18 +470,24 @@ class PowerSampler:
                 if ln.startswith("#"):
                     continue
                 f = ln.split()
-                if len(f) < 3 or not (t0 <= float(f[0]) <= t1):
+                if len(f) < 3:
                     continue
                 try:
-                    clk.append(float(f[1])); pw.append(float(f[2]))
-                    temp.append(float(f[3]))
+                    rec = (float(f[0]), float(f[1]), float(f[2]), float(f[3]))
                 except Exception:
-                    pass
+                    continue
+                allrec.append(rec)
         except Exception:
             return None
+        inside = [r for r in allrec if t0 <= r[0] <= t1]
+        how = "inside the timed region"
+        if not inside:  # a timed region shorter than the polling period: the samples right around it (same load: warm-up before, roofline pass after)
+            inside = [r for r in allrec if t0 - 0.02 <= r[0] <= t1 + 0.02]
+            how = "within 20 ms of the timed region (shorter than the polling period)"
+        clk, pw, temp = [r[1] for r in inside], [r[2] for r in inside], [r[3] for r in inside]
         if not clk:
             return None
-        return {"sclk_mhz": {"mean": round(sum(clk) / len(clk), 0), "min": min(clk), "max": max(clk)},
+        return {"window": how,"sclk_mhz": {"mean": round(sum(clk) / len(clk), 0), "min": min(clk), "max": max(clk)},
                 "socket_w": {"mean": round(sum(pw) / len(pw), 0), "max": max(pw)}, "power_limit_w": limit,
                 "hotspot_c_max": max(temp) if temp else None, "samples": len(clk),
                 "source": "amdsmi gpu_metrics (mean of the per-XCD gfx clocks, socket power), polled every ~2 ms by a helper process during the timed region"}
