@@ -419,8 +419,9 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
 # not importable on the host.
 # ---------------------------------------------------------------------------------------------------------------------
 _SAMPLER_SRC = r"""
-import sys, time
+import os, sys, time
 path, idx = sys.argv[1], int(sys.argv[2])
+parent = os.getppid()
 out = open(path, "w", buffering=1)
 try:
     import amdsmi
@@ -431,7 +432,7 @@ try:
 except Exception as e:
     out.write("# error %r\n" % (e,))
     sys.exit(0)
-while True:
+while os.getppid() == parent:  # (gone with the bench process, whatever happens to it)
     try:
         m = amdsmi.amdsmi_get_gpu_metrics_info(h)
         ck = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 60000]
