@@ -912,6 +912,31 @@ def test_swt_inverse_residue_major_rows_bit_identical():
         assert band_err(res[0], x) <= 1e-5
 
 
+def test_swt_fused_levels_18_and_20_taps():
+    """The fused SWT level kernels are instantiated up to 20 taps (db9, db10, sym9, sym10, coif3 ...; two-pass before): forward
+    bands against the oracle, inverse within the SWT tolerance, and against the two-pass path."""
+    rs = np.random.RandomState(41)
+    for wname in ("db9", "db10", "coif3"):
+        x = rs.uniform(0, 255, (512, 1024)).astype(np.float32)
+        W = pdwt_amd.Wavelets(x, wname, 3, do_swt=1)
+        O = orc.OracleWavelets(x, wname, 3, do_swt=1)
+        W.forward()
+        O.forward()
+        for g, o in zip(W.coeffs, O.coeffs):
+            assert band_err(g, o) <= 1e-5, wname
+        c = W.coeffs
+        W.inverse()
+        O.inverse()
+        assert band_err(W.get_image(), O.get_image()) <= 1e-5, wname
+        with knobs(swtf=0):
+            W2 = pdwt_amd.Wavelets(x, wname, 3, do_swt=1)
+            W2.forward()
+            for g, o in zip(c, W2.coeffs):
+                assert np.array_equal(g, o), wname  # forward: the same sums in the same order
+            W2.inverse()
+            assert band_err(W2.get_image(), W.get_image()) <= 1e-5
+
+
 def test_norm2sq_is_the_squared_l2_norm_in_1d():
     """the reference's 1-D norm2sq adds sum|d| of the detail bands (src/wt.cu:389); fixed here.  The knob
     norm2sq_ref1d = 1 reproduces the reference value."""
