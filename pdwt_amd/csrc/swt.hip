@@ -288,11 +288,13 @@ static int forward_swt(T* d_image, T** c, T* d_tmp, pdwt_info w, const typename 
     const T* in = d_image;
     const dim3 grid = swt_grid(w.Nr, w.Nc);
     for (int lev = 0; lev < w.nlevels; lev++) {
-        if constexpr (sizeof(T) == 4) {
-            // row pass + column pass in one launch (swt_fused.inc).  The approximation ping-pongs between the two halves
-            // of d_tmp (free on this path) because a single launch cannot read band 0 while it overwrites it.
+        {
+            // row pass + column pass in one launch (swt_fused.inc, swt_fused_f64.inc).  The approximation ping-pongs between the
+            // two halves of d_tmp (free on this path) because a single launch cannot read band 0 while it overwrites it.
             T* aout = (lev == w.nlevels - 1) ? c[0] : ((lev & 1) ? t2 : t1);
-            const int rr = swt_fwd_fused_f32(in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], w.Nr, w.Nc, w.hlen, 1 << lev, f);
+            int rr;
+            if constexpr (sizeof(T) == 4) rr = swt_fwd_fused_f32(in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], w.Nr, w.Nc, w.hlen, 1 << lev, f);
+            else rr = swt_fwd_fused_f64(in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], w.Nr, w.Nc, w.hlen, 1 << lev, f);
             if (rr < 0) return rr;
             if (rr == PDWT_OK) {
                 in = aout;
@@ -342,10 +344,12 @@ static int inverse_swt(T* d_image, T** c, T* d_tmp, pdwt_info w, const typename 
     const dim3 grid = swt_grid(w.Nr, w.Nc);
     const T* a = c[0];  // approximation feeding level i (band 0, or a half of d_tmp after a fused level)
     for (int i = w.nlevels - 1; i >= 0; i--) {
-        if constexpr (sizeof(T) == 4) {
-            // row + column synthesis in one launch (swt_fused.inc); the approximation ping-pongs through d_tmp
+        {
+            // row + column synthesis in one launch (swt_fused.inc, swt_fused_f64.inc); the approximation ping-pongs through d_tmp
             T* out = (i == 0) ? d_image : ((i & 1) ? t2 : t1);
-            const int rr = swt_inv_fused_f32(a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], out, w.Nr, w.Nc, w.hlen, 1 << i, f);
+            int rr;
+            if constexpr (sizeof(T) == 4) rr = swt_inv_fused_f32(a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], out, w.Nr, w.Nc, w.hlen, 1 << i, f);
+            else rr = swt_inv_fused_f64(a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], out, w.Nr, w.Nc, w.hlen, 1 << i, f);
             if (rr < 0) return rr;
             if (rr == PDWT_OK) {
                 a = out;

@@ -9,4 +9,8 @@ int swt_fwd_fused_f32(const float* in, float* cA, float* cH, float* cV, float* c
 // bands (Nr x Nc) -> out (Nr x Nc); taps = the inverse bank already halved (taps_inv(filt, 0.5)).  `out` must not alias an input.
 int swt_inv_fused_f32(const float* cA, const float* cH, const float* cV, const float* cD, float* out, int Nr, int Nc, int hlen, int fct,
                       const Taps2<float>& f);
+// double precision (swt_fused_f64.inc): same contracts, Nc even
+int swt_fwd_fused_f64(const double* in, double* cA, double* cH, double* cV, double* cD, int Nr, int Nc, int hlen, int fct, const Taps2<double>& f);
+int swt_inv_fused_f64(const double* cA, const double* cH, const double* cV, const double* cD, double* out, int Nr, int Nc, int hlen, int fct,
+                      const Taps2<double>& f);
 }  // namespace pdwt

@@ -937,6 +937,31 @@ def test_swt_fused_levels_18_and_20_taps():
             assert band_err(W2.get_image(), W.get_image()) <= 1e-5
 
 
+def test_swt_fused_levels_double_precision():
+    """swt_fused_f64.inc: one launch per SWT level in double precision.  Forward bands bit-identical to the two-pass kernels and
+    equal to the oracle; inverse (rows before columns, like the float32 fused inverse) within 1e-12 of both."""
+    rs = np.random.RandomState(43)
+    for wname, shape, lev in (("db7", (512, 1024), 4), ("db2", (300, 640), 3), ("sym8", (1024, 512), 5), ("haar", (256, 512), 4)):
+        x = rs.uniform(0, 255, shape)
+        res = []
+        for kn in (1, 0):
+            with knobs(swtf_f64=kn):
+                W = pdwt_amd.Wavelets(x, wname, lev, do_swt=1)
+                W.forward()
+                c = W.coeffs
+                W.inverse()
+                res.append((c, W.get_image()))
+        for k, (a, b) in enumerate(zip(res[0][0], res[1][0])):
+            assert np.array_equal(a, b), (wname, "band", k)
+        O = orc.OracleWavelets(x, wname, lev, do_swt=1)
+        O.forward()
+        for g, o in zip(res[0][0], O.coeffs):
+            assert band_err(g, o) <= 1e-12, wname
+        O.inverse()
+        assert band_err(res[0][1], O.get_image()) <= 1e-12, wname
+        assert band_err(res[0][1], res[1][1]) <= 1e-12, wname
+
+
 def test_norm2sq_is_the_squared_l2_norm_in_1d():
     """the reference's 1-D norm2sq adds sum|d| of the detail bands (src/wt.cu:389); fixed here.  The knob
     norm2sq_ref1d = 1 reproduces the reference value."""
