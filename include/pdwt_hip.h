@@ -210,6 +210,11 @@ int pdwt_sum_scratch_read(const double* d_scratch, double* out);
 /* same reduction, result in double regardless of T (used to combine shards across GPUs) */
 int pdwt_norm1_as_double_f32(float** d_coeffs, pdwt_info info, double* out);
 int pdwt_norm1_as_double_f64(double** d_coeffs, pdwt_info info, double* out);
+/* the same reduction, ENQUEUED only: partial sums and result go to `d_scratch` (pdwt_sum_scratch_doubles() doubles, owned by
+ * the caller); pdwt_sum_scratch_read fetches the value later.  Lets a host thread start the reductions of several devices
+ * before it waits for any of them (include/wt_batch.h). */
+int pdwt_norm1_enqueue_f32(float** d_coeffs, pdwt_info info, double* d_scratch);
+int pdwt_norm1_enqueue_f64(double** d_coeffs, pdwt_info info, double* d_scratch);
 
 /* ---------------------------------------------------------------------------------------------
  * Remaining coefficient utilities of the class and the circular shift of

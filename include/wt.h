@@ -69,10 +69,7 @@ class Wavelets {
   public:
     /* data members: order and types of src/wt.h:24-34 */
     DTYPE* d_image;        /* device: input image / reconstruction */
-    DTYPE** d_coeffs;      /* host array of device pointers: [A, H1,V1,D1, ...] or [A, D1, ...].  A caller that WRITES a band
-                              through these pointers must call coeff_int_ptr() once first (any index): soft_threshold() keeps
-                              sum|c| for the norm1() that follows it, and only coeff_int_ptr()/set_coeff() tell the class that
-                              the bands may change behind its back */
+    DTYPE** d_coeffs;      /* host array of device pointers: [A, H1,V1,D1, ...] or [A, D1, ...] */
     DTYPE* d_tmp;          /* device scratch */
     int current_shift_r;
     int current_shift_c;
@@ -108,6 +105,18 @@ class Wavelets {
     int add_wavelet(Wavelets W, DTYPE alpha = 1.0f);
     intptr_t image_int_ptr(void);
     intptr_t coeff_int_ptr(int num);
+
+    /* ADDITION (not in the reference).  By default norm1() reduces the bands every time it is called, exactly like the
+     * reference (src/wt.cu:398-418).  set_norm_cache(1) lets soft_threshold() accumulate sum|c| of the values it writes in
+     * the same pass and the norm1() that follows return it without touching the bands again.  Only opt in when nothing but
+     * the methods of this class writes the bands: a kernel or copy of the caller's that writes through d_coeffs[k] is
+     * invisible to the class (coeff_int_ptr() / set_coeff() are not -- they switch the shortcut off).  INTEGRATION.md B. */
+    void set_norm_cache(int on = 1);
+    /* ADDITIONS: norm1() in two halves, the value in double.  norm1_begin() only enqueues the reduction on the instance's
+     * device, norm1_end() waits for it and returns the sum before its rounding to DTYPE; wt_batch.h starts every shard's
+     * reduction before it reads the first one and adds the doubles. */
+    void norm1_begin();
+    double norm1_end();
 
   private:
     /* per-instance filter bank (the reference keeps it in process-global constant memory, so two

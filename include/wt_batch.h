@@ -74,11 +74,15 @@ class WaveletsBatch {
         for (size_t s = 0; s < shard.size(); s++)
             if (shard[s]) shard[s]->soft_threshold(beta, do_thresh_appcoeffs, normalize);
     }
+    /* every shard's reduction is enqueued on its device before the first result is read (the devices reduce concurrently),
+     * and the per-shard sums are added as doubles, before any rounding to DTYPE -- the value pdwt_amd/batch.py's all-reduce gives */
     double norm1()
     {
+        for (size_t s = 0; s < shard.size(); s++)
+            if (shard[s]) shard[s]->norm1_begin();
         double acc = 0.0;
         for (size_t s = 0; s < shard.size(); s++)
-            if (shard[s]) acc += (double)shard[s]->norm1();
+            if (shard[s]) acc += shard[s]->norm1_end();
         return acc;
     }
     /* the reconstructed batch, shards stacked in order; returns the element count */

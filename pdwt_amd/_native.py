@@ -42,7 +42,7 @@ PLAIN_SYMBOLS = ["pdwt_device_count", "pdwt_set_device", "pdwt_get_device", "pdw
                  "pdwt_graph_destroy", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set", "pdwt_debug_get",
                  "pdwt_sum_scratch_doubles", "pdwt_sum_scratch_read"]
 TYPED_SYMBOLS = (["compute_filters_separable", "create_coeffs_buffer", "free_coeffs_buffer", "copy_coeffs_buffer",
-                  "soft_thresh", "soft_thresh_sum", "norm1", "norm1_as_double", "hard_thresh", "proj_linf", "shrink", "group_soft_thresh",
+                  "soft_thresh", "soft_thresh_sum", "norm1", "norm1_as_double", "norm1_enqueue", "hard_thresh", "proj_linf", "shrink", "group_soft_thresh",
                   "norm2sq", "norm2sq_as_double", "add_coeffs", "circshift", "forward_nonseparable", "inverse_nonseparable",
                   "forward_swt_nonseparable", "inverse_swt_nonseparable"] + DRIVERS + HAAR_DRIVERS)
 
@@ -104,6 +104,7 @@ def hip():
         getattr(L, "pdwt_soft_thresh_" + sfx).argtypes = [PP, ct, Info, ci, ci]
         getattr(L, "pdwt_norm1_" + sfx).argtypes = [PP, Info, P]
         getattr(L, "pdwt_norm1_as_double_" + sfx).argtypes = [PP, Info, C.POINTER(C.c_double)]
+        getattr(L, "pdwt_norm1_enqueue_" + sfx).argtypes = [PP, Info, vp]
         for n in ("hard_thresh", "group_soft_thresh"):
             getattr(L, "pdwt_%s_%s" % (n, sfx)).argtypes = [PP, ct, Info, ci, ci]
         for n in ("proj_linf", "shrink"):
@@ -142,6 +143,7 @@ def host(dtype):
         L.pdwt_wavelets_norm1.argtypes = [vp]
         L.pdwt_wavelets_norm1_f64.restype = C.c_double
         L.pdwt_wavelets_norm1_f64.argtypes = [vp]
+        L.pdwt_wavelets_set_norm_cache.argtypes = [vp, ci]
         L.pdwt_wavelets_norm2sq.restype = ct
         L.pdwt_wavelets_norm2sq.argtypes = [vp]
         for n in ("hard_threshold", "group_soft_threshold"):

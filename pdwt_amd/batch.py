@@ -32,6 +32,9 @@ class ShardedBatch:
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # with a process group the collectives always run, also for world_size 1 (one code path; a 1-rank "nccl" group is how
+        # the RCCL branch is exercised on a 1-GPU box: tests/test_batch_gpu.py)
+        self.collective = dist.is_initialized()
         if engine_factory is None:
             import pdwt_amd
 
@@ -54,7 +57,7 @@ class ShardedBatch:
         """L1 norm of ALL coefficients of the whole batch: per-shard double partial + all-reduce(SUM)."""
         import torch
         local = float(self.W.norm1_f64())
-        if self.world == 1:
+        if not self.collective:
             return local
         dev = "cuda" if self.dist.get_backend(self.group) == "nccl" else "cpu"
         t = torch.tensor([local], dtype=torch.float64, device=dev)
@@ -66,7 +69,7 @@ class ShardedBatch:
         all-reduce of norm1() must add up to -- used by bench.py's untimed check of the N > 1 path."""
         import torch
         local = float(self.W.norm1_f64())
-        if self.world == 1:
+        if not self.collective:
             return [local]
         dev = "cuda" if self.dist.get_backend(self.group) == "nccl" else "cpu"
         t = torch.tensor([local], dtype=torch.float64, device=dev)
@@ -77,7 +80,7 @@ class ShardedBatch:
     def gather_image(self, dst=0):
         """All shards' reconstructed rows stacked in rank order on rank `dst` (None elsewhere)."""
         local = self.W.get_image()
-        if self.world == 1:
+        if not self.collective:
             return local
         out = [None] * self.world if self.rank == dst else None
         self.dist.gather_object(local, out, dst=dst, group=self.group)

@@ -20,7 +20,27 @@ struct CascMap {
     int cpx;     // W == 1: chunk rows per XCD (all 8 XCDs get the same number); W > 1: workgroups per XCD
     int strips;  // strips per chunk row
     int gy;      // W > 1: workgroup-chunk rows (gy * strips workgroups in all)
+    int stag;    // W > 1: hand-off ordered by LDS flags instead of barriers (free-running waves) when != 0; |stag| - 1 = start
+                 // skew between the four wave groups of a SIMD in units of 512 cycles (> 0: the bottom waves start first)
 };
+
+// ---- LDS flags of the workgroup cascade kernels (free-running waves) --------------------------------------------------
+// A producer wave publishes "my hand-off rows are in LDS" by storing a stage number into its flag word; the consumer (the
+// wave above) polls it right before its first read.  LDS operations of one wave execute in order and the flag is written
+// after an lgkmcnt(0), so data precedes flag; the consumer's acquire load keeps its reads behind the poll.
+__device__ __forceinline__ void casc_flag_publish(int* flag, int stage)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __hip_atomic_store(flag, stage, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void casc_flag_wait(int* flag, int stage)
+{
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < stage) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void casc_start_skew(int units)
+{
+    for (int i = 0; i < units; i++) __builtin_amdgcn_s_sleep(8);
+}
 struct CascBands {
     float *H1, *V1, *D1, *A2, *H2, *V2, *D2;
 };

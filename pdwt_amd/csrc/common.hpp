@@ -1,5 +1,6 @@
 // common.hpp -- internals shared by the HIP translation units of libpdwt_hip.so (gfx950 only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stddef.h>
@@ -49,7 +50,7 @@ enum KernelId {
     K_INV2D_STREAM,
     K_FWD2D_SMALL,   // register-tile kernels for the small, latency-bound levels (dwt_small.hip)
     K_INV2D_SMALL,
-    K_FWD2D_F64,     // fused row+column level kernels for long double-precision banks (dwt_f64_fused.hip)
+    K_FWD2D_F64,     // fused row+column level kernels for double-precision / long float32 banks (dwt_lds.hip)
     K_INV2D_F64,
     K_THRESH_SUM,    // soft threshold that also leaves sum|c| of the result behind (utils.hip)
     K_COUNT
@@ -72,6 +73,23 @@ struct KTimer {
         else hipLaunchKernelGGL(kernel, grid, block, lds, pdwt::stream(), __VA_ARGS__);                                    \
     } while (0)
 
+// More than 64 KB of dynamic LDS per workgroup is opt-in per (kernel, device).  The driver call is made ONCE for each pair
+// (one function-local static per kernel: the kernel is the template argument) and asks for the most a kernel can ever request
+// (160 KB), so afterwards nothing but the launch itself is on the enqueue path.
+template <auto Kernel>
+inline int lds_opt_in()
+{
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    PDWT_HIP_TRY(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_relaxed) & bit)) {
+        PDWT_HIP_TRY(hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        done.fetch_or(bit, std::memory_order_relaxed);
+    }
+    return PDWT_OK;
+}
+
 // ---- tuning / test knobs ------------------------------------------------------------------------
 // Every PDWT_* environment knob is read ONCE (first use of the table), never on the enqueue path; tests and tuning
 // scripts change a value at run time through pdwt_debug_set("<name>", value).  Names and meaning: INTEGRATION.md.
@@ -87,6 +105,8 @@ enum KnobId {
     KN_CASC_WG,            // forward cascade: waves stacked per workgroup with LDS ring hand-off (0 = auto, 1 = independent waves)
     KN_CASC_IWG,           // inverse cascade: the same (0 = auto, 1 = independent waves)
     KN_CASC_L3,            // 0: never fold a third level into the inverse cascade launch
+    KN_CASC_STAG,          // forward workgroup cascade: 0 = barriers order the LDS hand-off; != 0 = LDS flags (free-running waves), |v| - 1 = start skew per wave group (512-cycle units; > 0 bottom waves first)
+    KN_CASC_ISTAG,         // inverse workgroup cascade: the same
     KN_STREAM,             // 0: LDS-tiled fused level kernels instead of the streaming ones
     KN_STREAM_R,           // streaming level kernels: rows per wave (0 = auto)
     KN_STREAM_WAVES,       // streaming level kernels: target waves per launch
@@ -101,13 +121,12 @@ enum KnobId {
     KN_SWTF_XCD,           // fused SWT levels: XCD-aware tile order
     KN_SWTF_PERM,          // fused SWT inverse, tap spacing 4/8/16: residue-major LDS rows
     KN_SWTF_F64,           // 0: two-pass SWT in double precision instead of the fused per-level kernels
-    KN_F64_FUSED,
-    KN_F64_FUSED_MIN,      // fused long double-precision level kernels: smallest level side (pixels)
     KN_F64_LDS,            // LDS-ring form of the fused long double-precision level kernels (dwt_lds.hip)
     KN_F64_LDS_MIN,        // ... smallest level side (pixels)
     KN_F64_LDS_WGS,        // ... workgroups to aim for
     KN_F64_LDS_MINGROUPS,  // ... shortest chunk, in groups of 4 output rows
-    KN_NORM2SQ_REF1D,      // 1: norm2sq of a 1-D transform adds sum|d| of the detail bands like the reference (src/wt.cu:389) instead of sum d^2          // 0: two-pass form for long double-precision 2D levels instead of the fused row+column kernels
+    KN_NORM2SQ_REF1D,      // 1: norm2sq of a 1-D transform adds sum|d| of the detail bands like the reference (src/wt.cu:389) instead of sum d^2
+    KN_NORM_IN_THRESHOLD,  // sum|c| computed inside soft_threshold() and returned by the next norm1(): -1 = per instance (set_norm_cache), 0 = never, 1 = always
     KN_COUNT
 };
 int knob(KnobId id);

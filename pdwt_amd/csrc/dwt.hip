@@ -26,10 +26,10 @@
 #include "cols_ring.hpp"
 #include "rows_tr.hpp"
 #include "dwt1d_fused.hpp"
+#include "dwt_lds.hpp"
 #include "dwt_stream.hpp"
 #include "dwt_casc.hpp"
 #include "casc_dev.hpp"
-#include "dwt_f64_fused.hpp"
 
 namespace pdwt {
 
@@ -559,11 +559,9 @@ template <typename T>
 static int level_fwd2d(const T* in, T* cA, T* cH, T* cV, T* cD, T* t1, T* t2, size_t trash_floats, int nr, int nc, int hlen, const Taps2<T>& f,
                        T* taps_dev)
 {
-    if constexpr (sizeof(T) == 8) {  // long double-precision banks: row + column pass in one launch (dwt_f64_fused.hip)
+    if constexpr (sizeof(T) == 8) {  // double-precision banks: row + column pass in one launch (dwt_lds.hip)
         if (!force_twopass()) {
-            int rc = fwd2d_f64_lds(in, cA, cH, cV, cD, taps_dev, nr, nc, hlen, f);
-            if (rc <= 0) return rc;
-            rc = fwd2d_f64_fused(in, cA, cH, cV, cD, taps_dev, nr, nc, hlen, f);
+            const int rc = fwd2d_f64_lds(in, cA, cH, cV, cD, taps_dev, nr, nc, hlen, f);
             if (rc <= 0) return rc;
         }
     }
@@ -602,11 +600,9 @@ template <typename T>
 static int level_inv2d(const T* cA, const T* cH, const T* cV, const T* cD, T* out, T* t1, T* t2, int nri, int nci, int nro, int nco,
                        int hlen, const Taps2<T>& f, T* taps_dev)
 {
-    if constexpr (sizeof(T) == 8) {  // long double-precision banks: column + row synthesis in one launch (dwt_f64_fused.hip)
+    if constexpr (sizeof(T) == 8) {  // double-precision banks: column + row synthesis in one launch (dwt_lds.hip)
         if (!force_twopass()) {
-            int rc = inv2d_f64_lds(cA, cH, cV, cD, out, taps_dev, nri, nci, nro, nco, hlen, f);
-            if (rc <= 0) return rc;
-            rc = inv2d_f64_fused(cA, cH, cV, cD, out, taps_dev, nri, nci, nro, nco, hlen, f);
+            const int rc = inv2d_f64_lds(cA, cH, cV, cD, out, taps_dev, nri, nci, nro, nco, hlen, f);
             if (rc <= 0) return rc;
         }
     }

@@ -7,8 +7,8 @@
 // Reference code replaced: w_kern_forward_pass1 + w_kern_forward_pass2 (src/separable.cu:91-176) of one iteration of
 // w_forward_separable (:179-209).
 //
-// Why a second fused form (dwt_f64_fused.hip keeps the column ring in REGISTERS): a 40-row ring of (lo, hi) doubles is 160 VGPRs,
-// which pins that kernel at 2 waves per SIMD with no register left to prefetch its LDS window reads -- the VALU is busy 55-62 %
+// Why the ring is not in REGISTERS (the first fused form, removed in round 3, kept it there): a 40-row ring of (lo, hi) doubles is 160 VGPRs,
+// which pinned that kernel at 2 waves per SIMD with no register left to prefetch its LDS window reads -- the VALU is busy 55-62 %
 // of the time.  Here the ring lives in LDS and every thread is register-blocked over TWO outputs of the pass it runs:
 //   * a workgroup (256 threads, two per CU) owns 64 output columns and walks down a chunk, 8 input rows (4 output rows) per step;
 //   * ROW pass: thread = (input row, pair of adjacent output columns); its two 40-sample windows overlap in 38 samples, so 21
@@ -27,7 +27,7 @@
 //     base register + immediate.
 // Per-sample arithmetic: taps in ascending window position, one FMA per tap, rows before columns -- the reference's and the
 // oracle's order: bit-identical to the two-pass kernels (float32: two such FMAs per v_pk_fma_f32).
-#include "dwt_f64_fused.hpp"
+#include "dwt_lds.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -456,7 +456,7 @@ int fwd2d_f32_lds(const float* in, float* cA, float* cH, float* cV, float* cD, i
 //   window position p (coefficient rows p-C .. p-C+H2-1) -> output rows 2p-SHIFT (tap parity 1) and 2p+1-SHIFT (parity 0);
 //   the same along x: coefficient column c -> output columns 2c-SHIFT, 2c+1-SHIFT from t columns c-C .. c-C+H2-1.
 //
-// dwt_f64_fused.hip keeps rings of all four bands in every lane (184 VGPRs).  Here a thread owns ONE coefficient column of ONE band
+// The first fused form kept rings of all four bands in every lane (184 VGPRs).  Here a thread owns ONE coefficient column of ONE band
 // pair -- waves 0,1: (A, H) -> t1, waves 2,3: (V, D) -> t2 -- so its rings are half as large, and the row synthesis is register-blocked
 // over two adjacent coefficient columns (21 16-byte LDS reads of (t1, t2) pairs feed 160 FMAs; the fused kernel reads 40):
 //   * a workgroup owns 108 coefficient columns (+ H2-1 of halo = 127 threads per band pair) and walks down a chunk, two window

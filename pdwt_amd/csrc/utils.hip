@@ -534,9 +534,12 @@ static int group_soft_thresh(T** c, T beta, pdwt_info w, int do_thresh_appcoeffs
 //           (sum |c|) of the detail bands (src/wt.cu:389, SURVEY B-4): a bug, FIXED here (the squared l2 norm is
 //           returned); knob norm2sq_ref1d = 1 reproduces the reference value.
 template <typename T>
-static int band_sum_double(T** c, pdwt_info w, double* out, int squares, int ref_quirk_1d)
+static int band_sum_double(T** c, pdwt_info w, double* out, int squares, int ref_quirk_1d, double* scratch = nullptr)
 {
-    if (!c || !out) return PDWT_EINVAL;
+    // scratch != NULL: enqueue only -- the partials and the result land in the CALLER's device buffer (pdwt_sum_scratch_doubles()
+    // doubles; read later with pdwt_sum_scratch_read), nothing synchronises.  That is how the shards of a batch overlap their
+    // reductions (include/wt_batch.h).
+    if (!c || (!out && !scratch)) return PDWT_EINVAL;
     BandGeom g;
     if (band_geometry(w, &g) != PDWT_OK) return PDWT_EINVAL;
     BandTable<T> tab;
@@ -548,9 +551,10 @@ static int band_sum_double(T** c, pdwt_info w, double* out, int squares, int ref
         if (!table_push<T>(tab, c[k], (size_t)g.Nr[k] * g.Nc[k], sq ? T(1) : T(0), vec)) return PDWT_EINVAL;
     }
     int dev = 0;
-    double* part = partials(&dev);
+    double* part = scratch ? scratch : partials(&dev);
     if (!part) return PDWT_ENOMEM;
-    std::lock_guard<std::mutex> red_lock(g_red_mu[dev]);
+    std::unique_lock<std::mutex> red_lock(g_red_mu[scratch ? 0 : dev], std::defer_lock);
+    if (!scratch) red_lock.lock();  // the per-device partials are shared by every instance on that device
     const unsigned int total = tab.chunk0[tab.nb];
     const int blocks = (int)(total < (unsigned)kMaxBlocks ? (total ? total : 1) : (unsigned)kMaxBlocks);
     {
@@ -564,6 +568,7 @@ static int band_sum_double(T** c, pdwt_info w, double* out, int squares, int ref
         hipLaunchKernelGGL(k_abs_sum_final, dim3(1), dim3(kUThreads), 0, stream(), (const double*)part, blocks, part + kMaxBlocks);
         PDWT_CHECK_LAUNCH();
     }
+    if (scratch) return PDWT_OK;
     return pdwt_memcpy_d2h(out, part + kMaxBlocks, sizeof(double));
 }
 
@@ -636,6 +641,7 @@ using namespace pdwt;
     int pdwt_shrink_##SFX(T** c, T beta, pdwt_info w, int app) { return ew_bands<OP_SCALE, T>(c, beta, w, app, 0, K_SOFT_THRESH); }           \
     int pdwt_group_soft_thresh_##SFX(T** c, T beta, pdwt_info w, int app, int norm) { return group_soft_thresh<T>(c, beta, w, app, norm); }   \
     int pdwt_norm1_as_double_##SFX(T** c, pdwt_info w, double* out) { return band_sum_double<T>(c, w, out, 0, 0); }                          \
+    int pdwt_norm1_enqueue_##SFX(T** c, pdwt_info w, double* scratch) { return band_sum_double<T>(c, w, nullptr, 0, 0, scratch); }                          \
     int pdwt_norm2sq_as_double_##SFX(T** c, pdwt_info w, double* out) { return band_sum_double<T>(c, w, out, 1, 1); }                        \
     int pdwt_norm1_##SFX(T** c, pdwt_info w, T* out)                                                                                         \
     {                                                                                                                                        \

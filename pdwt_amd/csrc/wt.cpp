@@ -68,6 +68,10 @@ struct wstate_t {
     double* d_sum;
     int sum_valid;
     int raw_ptr_taken;
+    // OPT-IN (set_norm_cache): off, soft_threshold() runs the plain kernel and norm1() always reduces the bands, like the
+    // reference -- d_coeffs is a public member (src/wt.h:25), so the class cannot see a caller's kernel writing a band
+    int norm_cache;
+    int norm_enqueued;  // norm1_begin() has a reduction in flight into d_sum
 };
 static inline void coeffs_changed(void* st)
 {
@@ -220,6 +224,7 @@ Wavelets::Wavelets(const Wavelets& W)
             *F(filters_) = *F(W.filters_);
             WS(filters_)->dev = WS(W.filters_)->dev;
             WS(filters_)->raw_ptr_taken = WS(W.filters_)->raw_ptr_taken;  // (d_sum / sum_valid stay 0: the copy starts without a cached norm)
+            WS(filters_)->norm_cache = WS(W.filters_)->norm_cache;
             const size_t nb = 4 * (size_t)winfos.hlen * winfos.hlen * sizeof(DTYPE);
             for (int d = 0; d < 2; d++) {  // deep copy of the custom 2-D kernels
                 DTYPE* src = d ? WS(W.filters_)->d_k2i : WS(W.filters_)->d_k2f;
@@ -409,11 +414,33 @@ void Wavelets::inverse()
 }
 
 // ---- coefficient utilities -----------------------------------------------------------------------
-// PDWT_NORM_IN_THRESHOLD=0: soft_threshold() never computes the norm on the side (norm1() always reduces the bands)
-static bool norm_in_threshold()
+static double* sum_scratch(wstate_t* st)
 {
-    static const int on = getenv("PDWT_NORM_IN_THRESHOLD") ? atoi(getenv("PDWT_NORM_IN_THRESHOLD")) : 1;
-    return on == 1;
+    if (!st->d_sum) {
+        const size_t nb = pdwt_sum_scratch_doubles() * sizeof(double);
+        st->d_sum = (double*)pdwt_malloc(nb);
+        if (st->d_sum && pdwt_memset(st->d_sum, 0, nb) != PDWT_OK) {
+            pdwt_free(st->d_sum);
+            st->d_sum = NULL;
+        }
+    }
+    return st->d_sum;
+}
+
+// Knob "norm_in_threshold" (PDWT_NORM_IN_THRESHOLD; pdwt_debug_set): -1 = per instance (Wavelets::set_norm_cache, default
+// OFF: norm1() always reduces the bands), 0 = never, 1 = every instance (process-wide opt-in).  INTEGRATION.md section B.
+static bool norm_in_threshold(const wstate_t* st)
+{
+    int v = -1;
+    if (pdwt_debug_get("norm_in_threshold", &v) != PDWT_OK) v = -1;
+    return v < 0 ? st->norm_cache == 1 : v == 1;
+}
+
+void Wavelets::set_norm_cache(int on)
+{
+    if (!filters_) return;
+    WS(filters_)->norm_cache = on ? 1 : 0;
+    if (!on) WS(filters_)->sum_valid = 0;
 }
 
 void Wavelets::soft_threshold(DTYPE beta, int do_thresh_appcoeffs, int normalize)
@@ -427,15 +454,8 @@ void Wavelets::soft_threshold(DTYPE beta, int do_thresh_appcoeffs, int normalize
     coeffs_changed(filters_);
     wstate_t* st = WS(filters_);
     int rc;
-    if (st && !st->raw_ptr_taken && norm_in_threshold() && !(beta < (DTYPE)0)) {
-        if (!st->d_sum) {
-            const size_t nb = pdwt_sum_scratch_doubles() * sizeof(double);
-            st->d_sum = (double*)pdwt_malloc(nb);
-            if (st->d_sum && pdwt_memset(st->d_sum, 0, nb) != PDWT_OK) {
-                pdwt_free(st->d_sum);
-                st->d_sum = NULL;
-            }
-        }
+    if (st && !st->raw_ptr_taken && norm_in_threshold(st) && !(beta < (DTYPE)0)) {
+        (void)sum_scratch(st);
         if (st->d_sum) {
             rc = SFX(pdwt_soft_thresh_sum)(d_coeffs, beta, to_pdwt(winfos), do_thresh_appcoeffs, normalize, st->d_sum);
             if (rc == PDWT_OK) st->sum_valid = 1;
@@ -461,7 +481,7 @@ DTYPE Wavelets::norm1()
     if (state == W_CREATION_ERROR) return 0;
     wstate_t* st = WS(filters_);
     double d = 0;
-    if (st && st->sum_valid && st->d_sum && !st->raw_ptr_taken) {
+    if (st && st->sum_valid && st->d_sum && !st->raw_ptr_taken && norm_in_threshold(st)) {
         // the last soft_threshold() left sum|c| behind and no method has touched the bands since
         const int rc = pdwt_sum_scratch_read(st->d_sum, &d);
         if (rc == PDWT_OK) {
@@ -474,6 +494,40 @@ DTYPE Wavelets::norm1()
     if (rc != PDWT_OK) report("Wavelets::norm1()", rc);
     g_last_norm1 = d;
     return (DTYPE)d;
+}
+
+// norm1() in two halves (additions, include/wt.h): begin enqueues, end reads.  The scratch of the one-pass threshold is
+// reused: while its value is current (opted-in instances) nothing is launched at all.
+void Wavelets::norm1_begin()
+{
+    ON_MY_DEVICE();
+    if (state == W_CREATION_ERROR) return;
+    wstate_t* st = WS(filters_);
+    if (!st || !sum_scratch(st)) return;
+    if (st->sum_valid && !st->raw_ptr_taken && norm_in_threshold(st)) return;
+    const int rc = SFX(pdwt_norm1_enqueue)(d_coeffs, to_pdwt(winfos), st->d_sum);
+    if (rc != PDWT_OK) report("Wavelets::norm1_begin()", rc);
+    st->norm_enqueued = (rc == PDWT_OK);
+}
+
+double Wavelets::norm1_end()
+{
+    ON_MY_DEVICE();
+    if (state == W_CREATION_ERROR) return 0;
+    wstate_t* st = WS(filters_);
+    double d = 0;
+    const bool cached = st && st->sum_valid && st->d_sum && !st->raw_ptr_taken && norm_in_threshold(st);
+    if (st && st->d_sum && (cached || st->norm_enqueued)) {
+        st->norm_enqueued = 0;
+        const int rc = pdwt_sum_scratch_read(st->d_sum, &d);
+        if (rc == PDWT_OK) {
+            g_last_norm1 = d;
+            return d;
+        }
+        report("Wavelets::norm1_end()", rc);
+    }
+    (void)norm1();  // no scratch / nothing enqueued: the one-call path
+    return g_last_norm1;
 }
 
 // The remaining coefficient utilities (src/wt.cu:320-358): same state rule as soft_threshold.

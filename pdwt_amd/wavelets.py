@@ -65,10 +65,17 @@ def _device_source(img):
 
 
 class Wavelets:
-    def __init__(self, img, wname, levels, do_separable=1, do_cycle_spinning=0, do_swt=0, ndim=2, dtype=None, shape=None, device_ptr=None):
+    def __init__(self, img, wname, levels, do_separable=1, do_cycle_spinning=0, do_swt=0, ndim=2, dtype=None, shape=None, device_ptr=None,
+                 norm_cache=True):
         """Wavelets(img, Nr, Nc, wname, levels, memisonhost, do_separable, do_cycle_spinning, do_swt, ndim)
         (src/wt.h:42).  ``img`` is a 2-D (or 1-D) numpy array; or pass ``device_ptr`` + ``shape`` for
-        an image already in HBM (memisonhost=0), or img=None + shape for a zero image."""
+        an image already in HBM (memisonhost=0), or img=None + shape for a zero image.
+
+        ``norm_cache``: the C++ class reduces the bands on every ``norm1()`` unless ``set_norm_cache(1)`` was called
+        (include/wt.h: its ``d_coeffs`` is a public member, a caller's kernel may write a band unseen).  This wrapper
+        hands band pointers out ONLY through ``coeff_int_ptr`` / ``coeff_view``, which switch the shortcut off for the
+        instance, so it is safe by construction here and on by default: ``soft_threshold`` leaves sum|c| behind for the
+        ``norm1`` that follows.  ``norm_cache=False`` gives the reference behaviour."""
         N.require_gpu()
         dev = _device_source(img) if img is not None else None
         if dev is not None:  # image already in HBM: memisonhost = 0, the constructor copies device-to-device
@@ -100,6 +107,12 @@ class Wavelets:
         if not self._h:
             raise MemoryError("Wavelets allocation failed")
         self.wname = wname
+        if norm_cache:
+            self._L.pdwt_wavelets_set_norm_cache(self._h, 1)
+
+    def set_norm_cache(self, on=True):
+        """Wavelets::set_norm_cache (include/wt.h): norm1() right after soft_threshold() without a second pass."""
+        self._L.pdwt_wavelets_set_norm_cache(self._h, 1 if on else 0)
 
     @classmethod
     def _from_handle(cls, other, h):

@@ -103,6 +103,61 @@ def test_two_ranks_default_engine_nccl():
     _run("nccl")
 
 
+def _worker_one_rank_nccl(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    import pdwt_amd
+    from pdwt_amd.batch import ShardedBatch
+    torch.cuda.set_device(0)
+    assert pdwt_amd.hip().pdwt_set_device(0) == 0
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl"
+        x = np.random.RandomState(1).randn(37, 4096).astype(np.float32)
+        B = ShardedBatch(torch.from_numpy(x).cuda(), "sym8", 4, ndim=1)
+        assert B.collective and B.world == 1
+        B.forward()
+        n1 = B.norm1()               # float64 cuda tensor -> RCCL all-reduce(SUM)
+        parts = B.norm1_per_rank()   # RCCL all-gather
+        B.soft_threshold(0.25)
+        n1t = B.norm1()
+        B.inverse()
+        img = B.gather_image(0)      # gather_object over the nccl group
+        dist.barrier()
+        q.put((n1, parts, n1t, img))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(400)
+def test_one_rank_nccl_group_runs_the_rccl_branch():
+    """The first multi-GPU run must not be the first RCCL run: a world_size-1 "nccl" process group on the one GPU of the test
+    box loads RCCL, creates the communicator and pushes ShardedBatch.norm1() / norm1_per_rank() / gather_image() through the
+    cuda-tensor all-reduce / all-gather / gather_object branch that the 8-GPU bench takes; results equal the plain instance."""
+    import torch.multiprocessing as mp
+    import pdwt_amd
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_one_rank_nccl, args=(_free_port(), q))
+    p.start()
+    n1, parts, n1t, img = q.get(timeout=280)
+    p.join(60)
+    assert p.exitcode == 0
+    x = np.random.RandomState(1).randn(37, 4096).astype(np.float32)
+    W = pdwt_amd.Wavelets(x, "sym8", 4, ndim=1)
+    W.forward()
+    ref1 = W.norm1_f64()
+    assert n1 == ref1 and parts == [ref1]
+    W.soft_threshold(0.25)
+    assert n1t == W.norm1_f64()
+    W.inverse()
+    assert np.array_equal(img, W.get_image())
+
+
 @pytest.mark.parametrize("exe,shards", [("batch_demo", 3), ("batch_demod", 2), ("batch_demo", 8)])
 def test_one_process_batch_split_cpp(exe, shards):
     """include/wt_batch.h: the batch split driven from ONE host process through the C++ class (an instance per shard on

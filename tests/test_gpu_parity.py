@@ -248,10 +248,12 @@ def test_state_machine_and_errors():
 
 
 def test_config2_full_size_4096_db4_L3():
-    """BASELINE.json configs[1] at full size: HIP vs oracle on every band, round trip, and linearity."""
+    """BASELINE.json configs[1] at full size: HIP vs oracle on every band -- BIT FOR BIT (same taps, same FMA order: the
+    workgroup form of the cascade kernels at 4096^2 is checked against the oracle itself, not only against the other kernels) --
+    round trip, and linearity."""
     rs = np.random.RandomState(0)
     x = rs.uniform(0, 255, (4096, 4096)).astype(np.float32)
-    W, O = _check_against_oracle(x, "db4", 3)
+    W, O = _check_against_oracle(x, "db4", 3, exact=True)
     assert band_err(W.get_image(), x) <= 1e-5  # perfect reconstruction (orthogonal bank)
     # linearity: T(a*x + y) == a*T(x) + T(y) on the approximation band
     y = rs.uniform(0, 255, (4096, 4096)).astype(np.float32)
@@ -771,15 +773,15 @@ def test_stress_cascade_random_shapes():
 def test_f64_long_filter_level_kernels_random_shapes():
     """dwt_lds.hip (db20 / float64: both passes of a level in one launch, rings in LDS / split register rings) is the same
     arithmetic as the two-pass kernels, bit for bit, over random even shapes (strips that do not divide the width, chunks
-    shorter than the ring warm-up, depths down to 2x-the-filter levels), and as the older fused form where that one applies;
-    one geometry is also checked against the oracle."""
+    shorter than the ring warm-up, depths down to 2x-the-filter levels), and as whatever runs with these kernels switched off
+    (the LDS-tiled / two-pass kernels); one geometry is also checked against the oracle."""
     rs = np.random.RandomState(77)
     shapes = [(2 * rs.randint(64, 900), 2 * rs.randint(64, 900), rs.randint(1, 4)) for _ in range(14)]
     shapes += [(4096, 4096, 6), (512, 2048, 3), (2048, 256, 2), (8192, 1024, 4)]
     for nr, nc, lev in shapes:
         x = rs.uniform(-10, 10, (nr, nc))
         res = []
-        for kn in (dict(), dict(force_twopass=1), dict(f64_lds=0, f64_fused_min=0)):
+        for kn in (dict(), dict(force_twopass=1), dict(f64_lds=0)):
             with knobs(f64_lds_min=0, **kn):
                 W = pdwt_amd.Wavelets(x, "db20", lev)
                 W.forward()
@@ -1038,3 +1040,79 @@ def test_norm1_computed_inside_soft_threshold(case):
         A.forward()
         B.forward()
         assert abs(A.norm1_f64() - B.norm1_f64()) <= 1e-12 * B.norm1_f64()
+
+
+def test_norm1_default_of_the_class_sees_foreign_writes():
+    """Drop-in safety (include/wt.h): d_coeffs is a public member of the class (src/wt.h:25), so a caller's
+    own kernel may write a band without the class noticing.  The C++ class therefore reduces the bands on EVERY norm1()
+    unless set_norm_cache(1) / the knob opted in.  Here a band is zeroed behind the instance's back -- through the address
+    read out of the object's own d_coeffs table, the way `W.d_coeffs[1]` reads it in C++, without coeff_int_ptr() --
+    between soft_threshold() and norm1(): the default instance must report the new norm; the opted-in instance shows the
+    documented hazard (it still reports the value of the threshold pass); the process-wide knob overrides the instance."""
+    import ctypes as C
+    L = pdwt_amd.hip()
+    x = np.random.RandomState(5).uniform(-1, 1, (256, 384)).astype(np.float32) * 10
+    D = pdwt_amd.Wavelets(x, "db4", 2, norm_cache=False)   # what a C++ program gets from `Wavelets W(...)`
+    Cc = pdwt_amd.Wavelets(x, "db4", 2)                      # the Python wrapper's default: opted in
+
+    def band_ptr(W, k):  # Wavelets::d_coeffs is the second data member (after d_image): host table of device pointers
+        obj = C.cast(C.c_void_p(W._h), C.POINTER(C.c_void_p))
+        table = C.cast(C.c_void_p(obj[1]), C.POINTER(C.c_void_p))
+        return table[k]
+
+    for W in (D, Cc):
+        assert band_ptr(W, 0) and obj_image(W) == W.image_int_ptr()
+        W.forward()
+        W.soft_threshold(1.0)
+    nD0, nC0 = D.norm1_f64(), Cc.norm1_f64()
+    assert abs(nD0 - nC0) <= 1e-12 * nC0
+    r, c = D.band_shape(1)
+    for W in (D, Cc):
+        assert L.pdwt_memset(C.c_void_p(band_ptr(W, 1)), 0, r * c * 4) == 0   # the "foreign kernel": zero band 1
+        W.sync()
+    nD1, nC1 = D.norm1_f64(), Cc.norm1_f64()
+    bands = D.coeffs
+    assert not bands[1].any()
+    ref = float(sum(np.abs(b.astype(np.float64)).sum() for b in bands))
+    assert nD1 < nD0 and abs(nD1 - ref) <= 1e-9 * ref
+    assert nC1 == nC0, "opted-in instance: the documented hazard (value of the threshold pass)"
+    try:  # the knob overrides the per-instance setting
+        assert L.pdwt_debug_set(b"norm_in_threshold", 0) == 0
+        assert abs(Cc.norm1_f64() - nD1) <= 1e-12 * nD1
+    finally:
+        assert L.pdwt_debug_set(b"norm_in_threshold", -1) == 0
+
+
+def obj_image(W):
+    import ctypes as C
+    return C.cast(C.c_void_p(W._h), C.POINTER(C.c_void_p))[0]  # Wavelets::d_image, first data member
+
+
+def test_padded_banks_with_non_finite_samples():
+    """Banks whose length is not a multiple of 8 run the level kernels of dwt_lds.hip zero-padded to the next instantiated length
+    (DESIGN 3.3b).  The pad taps are multiplied and accumulated, so the result equals the exact-length kernels bit for bit on
+    FINITE data only: 0 * Inf = NaN reaches up to q = (H' - hlen) / 2 more window positions on either side of a non-finite
+    sample.  This pins the documented precondition: every coefficient that is finite in BOTH runs is
+    identical, the exact-length run's non-finite set is contained in the padded run's, and the extra ones sit within
+    ceil(q / 2) + 1 band samples of it."""
+    rs = np.random.RandomState(11)
+    x = rs.uniform(-5, 5, (256, 320))
+    x[100, 140] = np.inf
+    for wname, q in (("db5", 3), ("db7", 1)):
+        res = []
+        for kn in (dict(), dict(force_twopass=1)):
+            with knobs(f64_lds_min=0, **kn):
+                W = pdwt_amd.Wavelets(x, wname, 1)
+                W.forward()
+                res.append(W.coeffs)
+        reach = (q + 1) // 2 + 1
+        for k, (a, b) in enumerate(zip(*res)):
+            fa, fb = np.isfinite(a), np.isfinite(b)
+            assert not (fa & ~fb).any(), (wname, k, "the padded run must be non-finite wherever the exact-length run is")
+            both = fa & fb
+            assert np.array_equal(a[both], b[both]), (wname, k)
+            extra = np.argwhere(~fa & fb)
+            bad = np.argwhere(~fb)
+            assert len(bad) > 0
+            for (r, c) in extra:
+                assert (np.abs(bad - np.array([r, c])).max(axis=1) <= reach).any(), (wname, k, r, c)
