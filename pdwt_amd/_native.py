@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIBDIR = os.path.join(_PKG, "lib")
+# PDWT_LIBDIR: an alternative set of the in-tree libraries (diagnostic builds: tools/build_trace.sh, tools/ab_libs.sh)
+LIBDIR = os.environ.get("PDWT_LIBDIR") or os.path.join(_PKG, "lib")
 
 
 class Info(C.Structure):

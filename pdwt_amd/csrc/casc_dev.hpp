@@ -66,6 +66,34 @@ struct CascInvBands {
 };
 
 
+// ---- in-kernel timeline (diagnostic builds only: tools/build_trace.sh compiles the two cascade files with -DPDWT_CASC_TRACE) ----
+// Every wave keeps a few readings of the 100 MHz real-time counter in SGPRs and lane 0 stores them AFTER the final drain (the
+// hand-counted vmcnt pipeline never sees an extra store), at float offset kCascTraceOff of the trash area: 8 x u64 per wave,
+// wave id = blockIdx.x * W + wave (the inverse kernels one more kCascTraceOff further on, so that a forward / inverse pair can run
+// back to back).  tools/casc_trace.py reads them back and prints the launch ramp, the prologue, the per-phase
+// durations and the tail.
+constexpr size_t kCascTraceOff = 1u << 20;
+#ifdef PDWT_CASC_TRACE
+#define CASC_TRACE_DECL unsigned long long casc_tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define CASC_TRACE(i) casc_tr_[i] = wall_clock64()
+#define CASC_TRACE_STORE(trash, wave_id, aux)                                                             \
+    do {                                                                                                   \
+        if ((threadIdx.x & 63) == 0) {                                                                     \
+            unsigned long long* p_ = reinterpret_cast<unsigned long long*>((trash) + kCascTraceOff) + (size_t)(wave_id) * 8; \
+            for (int i_ = 0; i_ < 7; i_++) p_[i_] = casc_tr_[i_];                                          \
+            p_[7] = (unsigned long long)(aux);                                                             \
+        }                                                                                                  \
+    } while (0)
+#else
+#define CASC_TRACE_DECL
+#define CASC_TRACE(i)
+#define CASC_TRACE_STORE(trash, wave_id, aux)
+#endif
+
+// dwt_casc_inv3.hip: three levels, all streamed (hlen 4 and 8); 1 = not taken
+int inv2d_casc3_f32(const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1, const float* A3,
+                    const float* H3, const float* V3, const float* D3, float* out, float* trash, int nr, int nc, int hlen, const Taps2<float>& f);
+
 int inv2d_cascw_f32(const float* A2, const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1,
                     const float* A3, const float* H3, const float* V3, const float* D3, float* out, float* trash, int nr, int nc, int hlen,
                     const Taps2<float>& f);

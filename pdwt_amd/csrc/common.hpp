@@ -104,9 +104,10 @@ enum KnobId {
     KN_CASC_IPFD,          // inverse cascade: prefetch distance in steps
     KN_CASC_WG,            // forward cascade: waves stacked per workgroup with LDS ring hand-off (0 = auto, 1 = independent waves)
     KN_CASC_IWG,           // inverse cascade: the same (0 = auto, 1 = independent waves)
-    KN_CASC_L3,            // 0: never fold a third level into the inverse cascade launch
+    KN_CASC_L3,            // third level folded into the inverse cascade launch: 1 = streamed (dwt_casc_inv3.hip) where it applies, 2 = prologue form only, 0 = never
     KN_CASC_STAG,          // forward workgroup cascade: 0 = barriers order the LDS hand-off; != 0 = LDS flags (free-running waves), |v| - 1 = start skew per wave group (512-cycle units; > 0 bottom waves first)
     KN_CASC_ISTAG,         // inverse workgroup cascade: the same
+    KN_CASC_LDSPAD,        // workgroup cascades: request at least this many KB of LDS per workgroup (occupancy experiments)
     KN_STREAM,             // 0: LDS-tiled fused level kernels instead of the streaming ones
     KN_STREAM_R,           // streaming level kernels: rows per wave (0 = auto)
     KN_STREAM_WAVES,       // streaming level kernels: target waves per launch

@@ -65,6 +65,8 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
     using G = CascGeom<HLEN>;
     constexpr int C = G::C, NB1 = G::NB1, NB2 = G::NB2, NBT = G::NBT, WIN1 = G::WIN1, WIN2 = G::WIN2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    CASC_TRACE_DECL;
+    CASC_TRACE(0);
     const int lane = threadIdx.x & 63;
     const int Nc2 = Nc >> 1, Nr2 = Nr >> 1, Nr4 = Nr >> 2, Nc4 = Nc >> 2;
     // the wave index is uniform, but only readfirstlane tells the compiler: everything derived from it (rows, row
@@ -212,7 +214,9 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
     float* const tr = trash + (size_t)(blockIdx.x & 15) * Nc2;  // a trash ROW (the dispatcher checks the area holds 16 of them)
     const unsigned off1 = (unsigned)(valid ? x >> 1 : 0) * 4u, off2 = (unsigned)(valid ? x >> 2 : 0) * 4u;
     const lanemask_t vmask = __ballot(valid);
+    CASC_TRACE(1);  // ring prologue computed (its loads landed)
     static_for<NV>([&](auto K) { asm_drain1(v[decltype(K)::value]); });
+    CASC_TRACE(2);  // first body's rows landed
     auto a1_row = [&](auto A, int sb) {
             constexpr int a = decltype(A)::value;  // A1 row within the super-body
             constexpr int u = a % (HLEN / 2);
@@ -308,14 +312,23 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
         if constexpr (W > 1) {
             if (sb == 0 && !flags) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+#ifdef PDWT_CASC_TRACE
+        if (sb == 0) CASC_TRACE(3);  // first half super-body done
+#endif
         if (sb * HLEN + HLEN / 2 >= NA1) break;
         static_for<HLEN / 2>([&](auto U) { a1_row(std::integral_constant<int, decltype(U)::value + HLEN / 2>{}, sb); });
         if constexpr (W > 1) {
             if (sb == 0 && !flags) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+#ifdef PDWT_CASC_TRACE
+        if (sb == 0) CASC_TRACE(4);  // first super-body done
+#endif
         if (sb * HLEN + HLEN >= NA1) break;
     }
+    CASC_TRACE(5);  // loop left
     static_for<NV>([&](auto K) { asm_drain1(v[decltype(K)::value]); });
+    CASC_TRACE(6);  // everything this wave issued has retired
+    CASC_TRACE_STORE(trash, blockIdx.x * W + kw, ((unsigned long long)NA1 << 32) | (unsigned)rows2);
 }
 
 // =================================================================================================
@@ -644,7 +657,9 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
             const int nwg = gy * strips;
             const CascMap cm = {idiv_up(nwg, 8), strips, gy, knob(KN_CASC_STAG)};
             const dim3 grid((unsigned)(8 * cm.cpx));
-            const size_t lds = (size_t)(W - 1) * REG + 64 * sizeof(int);  // hand-off regions + flag words
+            size_t lds = (size_t)(W - 1) * REG + 64 * sizeof(int);  // hand-off regions + flag words
+            // (tuning: a larger LDS request lowers the workgroups per CU, i.e. turns a resident grid into an oversubscribed one)
+            if (knob(KN_CASC_LDSPAD) > 0) lds = std::max(lds, (size_t)knob(KN_CASC_LDSPAD) * 1024);
             // (HLEN row registers in flight instead of HLEN/2 measured slower in this form too: 24.8 vs 24.6 us at W = 8)
             void (*k)(const float*, CascBands, int, int, int, float*, CascMap, TapsLH);
             k = (W == 4) ? k_fwd2d_casc<HLEN, NVD, 4> : (W == 8) ? k_fwd2d_casc<HLEN, NVD, 8> : k_fwd2d_casc<HLEN, NVD, 16>;

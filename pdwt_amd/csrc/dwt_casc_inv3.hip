@@ -1,108 +1,111 @@
-// dwt_casc_invw.hip -- inverse 2D DWT, TWO or THREE levels per launch, float32, workgroup form.
+// dwt_casc_inv3.hip -- inverse 2D DWT, THREE levels per launch, float32, workgroup form, all three levels STREAMED.
 //
-// Same per-wave arithmetic as k_inv2d_casc (dwt_casc.hip: level-(l+1) column synthesis -> DPP halo -> row synthesis ->
-// two rows of A_l in registers -> level-l ring with the H,V,D rows -> output rows), organised differently:
+// k_inv2d_cascw<.., L3 = true> (dwt_casc_invw.hip) folds the third level in with a prologue: every wave synthesises all the
+// A_{l+1} rows it owns from the level-(l+2) bands into private LDS rows before its first step.  In-kernel timestamps
+// (tools/casc_trace.py, profiles/r03_c2_timeline.md) show what that costs at C2: 6.2-6.8 us pass before ANY wave emits its first
+// row (63 loads per lane, ~630 VALU, an LDS round trip, every wave in the same phase) in a kernel whose steady-state loop
+// moves 7.6 TB/s -- a quarter of the launch is dead time.  Here the third level is a third ring:
 //
-//  * W waves of a workgroup are stacked vertically in ONE strip.  A wave OWNS the level-(l+1) coefficient rows
-//    [Q0, Q0+nQ) it loads first-hand and emits exactly the rows whose synthesis windows START there:
-//      level-(l+1) window start q   ->  A_l rows      2(q+C)-SHIFT, +1      (stream r1 = 0 <-> A_l row P0 = 2(Q0+C)-SHIFT)
-//      level-l     window start p   ->  output rows   2(p+C)-SHIFT, +1      (stream g  = 0 <-> output row O0 = 2(P0+C)-SHIFT)
-//    The last H2-1 windows of either level reach into the rows of the wave BELOW: that wave has them in its rings anyway
-//    (its first H2-1 ring rows) and drops them in LDS during its first steps; a barrier after each of those steps orders
-//    the hand-off, and a wave picks its bottom halo up at the END of its chunk.  Only the last wave of a workgroup loads
-//    (level l+1: H2-1 rows + the windows of XS extra steps) and recomputes the halo, as every wave of k_inv2d_casc does.
-//  * L3: the approximation band of level l+1 is not read from memory at all.  Every wave synthesises the A_{l+1} rows it
-//    owns from the level-(l+2) bands in a prologue (redundant only in the H2-1 window rows: level l+2 is 1/16 of the data)
-//    into a private LDS area and reads them from there -- the level-(l+2) inverse launch (4.8 us at C2, latency-bound) and
-//    the round trip of A_{l+1} through memory disappear.
-// Reference code replaced: two / three iterations of the level loop of w_inverse_separable (src/separable.cu:332-364) with
-// their two kernels each (:246-328).
-#include "casc_dev.hpp"
-#include "dwt_stream.hpp"
+//   level l+2 ring (H2 rows of (A,V) and (H,D), lane = ONE level-(l+2) column)  -- one new row every SECOND step
+//     -> column synthesis, DPP halo, row synthesis: the lane's two A_{l+1} columns (same arithmetic as level l+1 -> A_l)
+//     -> two ds_bpermute + a select move them to the main mapping (lane = one level-(l+1) column)
+//   level l+1 ring  -- the A part of the new row is that value, V / H / D come from memory      -- one new row per step
+//   level l   ring  -- as in k_inv2d_cascw                                                       -- two new rows per step
+//
+// so the prologue shrinks to the three ring warm-ups (one round trip of loads, three small syntheses), no private LDS rows
+// exist (W = 16 waves fit: 138 KB of hand-off regions) and the A_{l+1} rows a wave gets from the wave below arrive through the
+// existing hand-off (they carry their A part).  A_{l+1} rows come in pairs from one level-(l+2) window (tap parity 1, then 0);
+// chunks start at EVEN level-(l+1) rows, so the pair phase is a compile-time constant and a step's parity decides whether the
+// level-(l+2) ring advances (even steps) -- H2 must be even for the unrolled super-body to see a constant parity: db2 and
+// db4 / sym4 (hlen 4 and 8); other lengths keep the prologue form.
+// Results are bit-identical to the per-level kernels (same taps, same FMA order per output).
+// Reference code replaced: three iterations of the level loop of w_inverse_separable (src/separable.cu:332-364), two kernels
+// each (:246-328).
 #include <algorithm>
 
+#include "casc_dev.hpp"
+#include "dwt_stream.hpp"
 #include "stream_dev.hpp"
 
 namespace pdwt {
 
-struct CascInv3 {
+struct CascInv3B {
     const float *A3, *H3, *V3, *D3;
 };
 
-// LDS hand-off region of one CONSUMER wave: (H2-1) level-(l+1) ring rows (A,V,H,D of the lane's column: 16 B) and
-// (H2-1) level-l ring rows (the lane's two columns of A,H,V,D: 32 B)
 template <int HLEN>
-constexpr int casc_inv_region_bytes() { return (HLEN / 2 - 1) * 64 * (16 + 32); }
-constexpr int kInvA2Rows = 16;  // three-level form: private A_{l+1} rows per wave (stream rows, 256 B each)
-constexpr int kInvR3Max = 12;   // ... and level-(l+2) rows a wave may load for them
+constexpr int casc_inv3_region_bytes() { return (HLEN / 2 - 1) * 64 * (16 + 32); }
 
-template <int HLEN, int W, bool L3>
-__global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3 b3, float* __restrict__ out, int Nr, int Nc, int VL,
+template <int HLEN, int W>
+__global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3B b3, float* __restrict__ out, int Nr, int Nc, int VL,
                                                          float* __restrict__ trash, CascMap cm, Taps2<float> f)
 {
     using G = CascInvGeom<HLEN>;
     constexpr int H2 = G::H2, C = G::C, SHIFT = G::SHIFT, NB1 = G::NB1, NB2 = G::NB2, NBT = G::NBT, WIN1 = G::WIN1, WIN2 = G::WIN2;
-    constexpr int XS = H2 / 2;                 // extra (level-l only) steps that drain the last H2-1 level-l windows
-    constexpr int NL2 = L3 ? 3 : 4;            // level-(l+1) loads per step
-    constexpr int kWait2 = 2 * (3 + 2);        // VMEM between a step's level-(l+1) loads and their use one step later
-    constexpr int kWait1 = 2 + (3 + 2) + NL2;  // ... between an A_l row's loads and their use one step later
+    static_assert(H2 % 2 == 0, "the parity of a step must be a compile-time constant of the unrolled super-body");
+    constexpr int XS = H2 / 2;   // extra (level-l only) steps that drain the last H2-1 level-l windows
+    constexpr int PHI = SHIFT;   // chunks start at even level-(l+1) rows: stream row s2 is output (s2 + PHI) & 1 of level-(l+2) step (s2 + PHI) >> 1
+    constexpr int T0 = (H2 - 1 + PHI) >> 1;  // level-(l+2) step of loop step 0 (whose new row s2 = H2-1 is the FIRST of a pair)
+    static_assert(((H2 - 1 + PHI) & 1) == 0, "loop step 0 starts a level-(l+2) window");
+    constexpr int NW3 = H2 + T0 - 1;         // level-(l+2) rows the warm-up windows t = 0 .. T0-1 span
+    // VMEM instructions between a load and its use (stream_dev.hpp); E = the step is even (4 level-(l+2) loads are issued first)
+    constexpr int kStep = 3 + 2 * (3 + 2);   // odd step: 3 level-(l+1) loads + per A_l row 3 loads and 2 stores
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     CASC_TRACE_DECL;
     CASC_TRACE(0);
     const int lane = threadIdx.x & 63;
     const int kw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int Nr1 = Nr >> 1, Nc1 = Nc >> 1, Nr2 = Nr >> 2, Nc2 = Nc >> 2;
-    // workgroup -> (workgroup-chunk row, strip); XCD x owns the logical workgroups [x*cpx, (x+1)*cpx)
+    const int Nr1 = Nr >> 1, Nc1 = Nc >> 1, Nr2 = Nr >> 2, Nc2 = Nc >> 2, Nr3 = Nr >> 3, Nc3 = Nc >> 3;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int wg = xcd * cm.cpx + slot;
     if (slot >= cm.cpx || wg >= cm.gy * cm.strips) return;  // (uniform over the workgroup: nobody is left at a barrier)
     const int gy = wg / cm.strips, strip = wg % cm.strips;
-    const int J0 = (int)(((long long)gy * Nr2) / cm.gy);
-    const int R = (int)(((long long)(gy + 1) * Nr2) / cm.gy) - J0;
-    // split of the R level-(l+1) rows: the last wave runs XS steps more than it owns rows (the recomputed halo);
-    // the host guarantees R / W >= H2
-    const int E = min(XS, R / W - 1);
-    const int base = (R + E) / W, rem = (R + E) % W;
-    const int start = kw * base + min(kw, rem);
-    const int nQ = (kw < W - 1) ? base + (kw < rem ? 1 : 0) : R - start;
-    const int Q0 = J0 + start;
+    // rows are dealt in PAIRS (see PHI): workgroup chunk [J0, J0 + R), wave chunk [Q0, Q0 + nQ), all even
+    const int Np = Nr2 >> 1;
+    const int Jp = (int)(((long long)gy * Np) / cm.gy);
+    const int Rp = (int)(((long long)(gy + 1) * Np) / cm.gy) - Jp;
+    // the last wave runs XS steps more than it owns rows (the recomputed halo): it gets XS rows (XS / 2 pairs, at least one) fewer
+    const int Ep = min(max(XS / 2, 1), max(Rp / W - 1, 0));
+    const int basep = (Rp + Ep) / W, remp = (Rp + Ep) % W;
+    const int startp = kw * basep + min(kw, remp);
     const bool last = (kw == W - 1);
+    const int nQ = 2 * (last ? Rp - startp : basep + (kw < remp ? 1 : 0));
+    const int Q0 = 2 * (Jp + startp);
     const int nsteps = nQ + XS;
     const int P0 = 2 * (Q0 + C) - SHIFT;  // A_l row of stream index r1 = 0
     const int O0 = 2 * (P0 + C) - SHIFT;  // output row of stream index g = 0
     const int nP = 2 * nQ;                // level-l windows (= output row pairs) the wave owns
-    // last stream rows the wave loads itself
-    const int last2 = last ? H2 - 2 + nsteps : nQ - 1;
+    const int last2 = last ? H2 - 2 + nsteps : nQ - 1;  // last stream rows the wave loads (or synthesises) itself
     const int last1 = last ? 2 * nsteps - 1 : nP - 1;
+    const int P3_0 = (Q0 + SHIFT) >> 1;                 // level-(l+2) pair index of level-(l+2) step t = 0
+    const int last3 = ((last2 + PHI) >> 1) + H2 - 1;    // last level-(l+2) stream row (i = 0 <-> row P3_0 - C) the wave needs
 
-    const int cx1 = strip * VL * 2 + 2 * (lane - NBT);  // first of the lane's two level-l coefficient columns
+    const int X0 = strip * VL - NBT;               // level-(l+1) column of lane 0 (may be negative: periodic)
+    const int cx1 = 2 * (X0 + lane);               // first of the lane's two level-l coefficient columns
     const bool valid = (lane >= NBT) && (lane < NBT + VL) && (cx1 < Nc1);
     const int cx1w = wrapi(cx1, Nc1);
     const int cx2w = cx1w >> 1;
-    const float* const pA2 = b.A2 + cx2w;
-    const float* const pH2 = b.H2 + cx2w;
-    const float* const pV2 = b.V2 + cx2w;
-    const float* const pD2 = b.D2 + cx2w;
-    const float* const pH1 = b.H1 + cx1w;
-    const float* const pV1 = b.V1 + cx1w;
-    const float* const pD1 = b.D1 + cx1w;
-    // single conditional wraps: Q0 < Nr2, P0 < Nr1 + 2C, O0 < Nr + 6C and a wave's rows are few (the host keeps chunks < Nr2/2)
+    // level l+2: lane <-> column c3 = (X0 >> 1) - C + lane; its two A_{l+1} columns are 2 c3, 2 c3 + 1.  The lane of the main
+    // mapping that holds A_{l+1} column X = X0 + lane takes it from level-(l+2) lane (X >> 1) - (X0 >> 1) + C, output X & 1.
+    const int c3w = wrapi((X0 >> 1) - C + lane, Nc3);
+    const int bp_addr = 4 * (((X0 + lane) >> 1) - (X0 >> 1) + C);
+    const bool bp_odd = ((X0 + lane) & 1) != 0;
+
+    auto off3 = [&](int i) { return (size_t)wrapi(P3_0 - C + i, Nr3) * Nc3; };
     auto off2 = [&](int s2) { return (size_t)wrap1(Q0 + s2, Nr2) * Nc2; };
     auto off1 = [&](int r1) { return (size_t)wrap1(P0 + r1, Nr1) * Nc1; };
-    const unsigned voff2 = (unsigned)cx2w * 4u, voff1 = (unsigned)cx1w * 4u, voffo = (unsigned)(valid ? cx1 : 0) * 8u;
+    const unsigned voff3 = (unsigned)c3w * 4u, voff2 = (unsigned)cx2w * 4u, voff1 = (unsigned)cx1w * 4u, voffo = (unsigned)(valid ? cx1 : 0) * 8u;
     const lanemask_t vmask = __ballot(valid);
 
-    // LDS: [hand-off regions][private A_{l+1} rows]
-    constexpr int REG = casc_inv_region_bytes<HLEN>();
+    // LDS: [hand-off regions][flag words]
+    constexpr int REG = casc_inv3_region_bytes<HLEN>();
     unsigned char* const lds_rd = lds_raw + (size_t)kw * REG;                    // written by wave kw+1
     unsigned char* const lds_wr = lds_raw + (size_t)(kw > 0 ? kw - 1 : 0) * REG;  // read by wave kw-1
     auto lds_l2 = [&](unsigned char* reg, int r) { return reinterpret_cast<v4f*>(reg + ((size_t)r * 64 + lane) * 16); };
     auto lds_l1 = [&](unsigned char* reg, int r, int h) {
         return reinterpret_cast<v4f*>(reg + (size_t)(H2 - 1) * 64 * 16 + (((size_t)r * 2 + h) * 64 + lane) * 16);
     };
-    float* const lds_a2 = reinterpret_cast<float*>(lds_raw + (size_t)(W - 1) * REG + (size_t)kw * kInvA2Rows * 256);
-    // free-running form (cm.stag != 0): flag word k is written by wave k (stage 1: level-(l+1) ring rows in LDS, stage 2: level-l rows too)
-    int* const lds_flags = reinterpret_cast<int*>(lds_raw + (size_t)(W - 1) * REG + (L3 ? (size_t)W * kInvA2Rows * 256 : 0));
+    int* const lds_flags = reinterpret_cast<int*>(lds_raw + (size_t)(W - 1) * REG);
     const bool flags = cm.stag != 0;
     if (flags) {
         if (lane == 0) lds_flags[kw] = 0;
@@ -111,12 +114,14 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
         casc_start_skew(d * (cm.stag > 0 ? (W - 1 - kw) >> 2 : kw >> 2));
     }
 
+    v2f r3av[H2], r3hd[H2];               // level l+2 ring, oldest row in slot 0 (rotated by moves: it advances every second step)
     v2f r2av[H2], r2hd[H2];               // level l+1 ring: (A,V) and (H,D) of the lane's column
     v2f ra[H2], rh[H2], rv[H2], rd[H2];   // level l ring: the lane's two columns of each band
 #pragma unroll
     for (int k = 0; k < H2; k++) ra[k] = rh[k] = rv[k] = rd[k] = v2f{0.f, 0.f};
 
-    // one row of A_l (the lane's two columns) from a level-(l+1)-style ring window starting at slot S0, tap parity OFF
+    // two adjacent outputs (the columns 2c, 2c+1 of a lane that holds coefficient column c) of one synthesis level from the ring
+    // window av / hd starting at slot S0 with tap parity OFF: column synthesis -> DPP halo of (t1, t2) -> row synthesis
     auto synth_pair = [&](const v2f (&av)[H2], const v2f (&hd)[H2], auto S0, auto OFF, float& a0, float& a1) {
         constexpr int s0 = decltype(S0)::value, off = decltype(OFF)::value;
         v2f sav = {0.f, 0.f}, shd = {0.f, 0.f};
@@ -155,87 +160,75 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
         a0 = o2[0];
         a1 = o2[1];
     };
+    // one A_{l+1} value per lane of the main mapping from a level-(l+2) window
+    auto a2_from = [&](const v2f (&av)[H2], const v2f (&hd)[H2], auto OFF) {
+        float a0, a1;
+        synth_pair(av, hd, std::integral_constant<int, 0>{}, OFF, a0, a1);
+        const int g0 = __builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(a0));
+        const int g1 = __builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(a1));
+        return __int_as_float(bp_odd ? g1 : g0);
+    };
 
-    // ring warm-up rows and the first row registers: issued BEFORE the three-level prologue so that their latency overlaps it
-    float q2[4];   // row registers in flight, level l+1 (prefetch distance: one step)
-    v2f q1[2][3];  // row registers in flight, level l (two A_l rows per step)
+    // ---- ring warm-up rows of all three levels and the first row registers, issued together ----------------------------
+    float q3[4];   // row registers in flight, level l+2 (the row the NEXT even step inserts)
+    float q2[4];   // level l+1 (prefetch distance: one step); q2[0] is unused (the A part is synthesised)
+    v2f q1[2][3];  // level l (two A_l rows per step)
     {
+        v2f w3av[NW3], w3hd[NW3];
+#pragma unroll
+        for (int i = 0; i < NW3; i++) {
+            const size_t o = off3(min(i, last3)) + c3w;
+            w3av[i] = v2f{b3.A3[o], b3.V3[o]};
+            w3hd[i] = v2f{b3.H3[o], b3.D3[o]};
+        }
+        {
+            const size_t o = off3(min(NW3, last3)) + c3w;
+            q3[0] = b3.A3[o];
+            q3[1] = b3.H3[o];
+            q3[2] = b3.V3[o];
+            q3[3] = b3.D3[o];
+        }
 #pragma unroll
         for (int r = 0; r < H2 - 1; r++) {
-            const size_t o = off2(r);
-            r2av[r] = v2f{L3 ? 0.f : pA2[o], pV2[o]};
-            r2hd[r] = v2f{pH2[o], pD2[o]};
+            const size_t o = off2(r) + cx2w;
+            r2av[r] = v2f{0.f, b.V2[o]};
+            r2hd[r] = v2f{b.H2[o], b.D2[o]};
         }
         r2av[H2 - 1] = r2hd[H2 - 1] = v2f{0.f, 0.f};
         {
-            const size_t o = off2(H2 - 1);
-            q2[0] = L3 ? 0.f : pA2[o];
-            q2[1] = pH2[o];
-            q2[2] = pV2[o];
-            q2[3] = pD2[o];
+            const size_t o = off2(H2 - 1) + cx2w;
+            q2[0] = 0.f;
+            q2[1] = b.H2[o];
+            q2[2] = b.V2[o];
+            q2[3] = b.D2[o];
         }
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            const size_t o = off1(q);
-            q1[q][0] = *reinterpret_cast<const v2f*>(pH1 + o);
-            q1[q][1] = *reinterpret_cast<const v2f*>(pV1 + o);
-            q1[q][2] = *reinterpret_cast<const v2f*>(pD1 + o);
+            const size_t o = off1(q) + cx1w;
+            q1[q][0] = *reinterpret_cast<const v2f*>(b.H1 + o);
+            q1[q][1] = *reinterpret_cast<const v2f*>(b.V1 + o);
+            q1[q][2] = *reinterpret_cast<const v2f*>(b.D1 + o);
         }
-    }
-    // ---- three-level form: the wave's A_{l+1} rows from the level-(l+2) bands, into its private LDS rows ----------
-    if constexpr (L3) {
-        const int Nr3 = Nr >> 3, Nc3 = Nc >> 3;
-        const int nA2 = min(last ? H2 - 1 + nsteps : nQ, kInvA2Rows);  // stream rows s2 in [0, nA2) are read from here
-        // pair index P3 <-> A_{l+1} rows 2*P3-SHIFT, +1  (window start P3 - C)
-        const int P3a = (Q0 + SHIFT) >> 1, P3b = (Q0 + nA2 - 1 + SHIFT) >> 1;
-        const int np = P3b - P3a + 1;    // pairs to synthesise
-        const int nr3 = np + H2 - 1;     // level-(l+2) rows needed (<= kInvR3Max, checked by the host)
-        // lane <-> level-(l+2) column; its two A_{l+1} columns are 2*c3, 2*c3+1; lanes [C, 64-C) are valid after the DPP halo
-        const int a2c0 = strip * VL - NBT;                    // A_{l+1} column of lane 0 in the main mapping (may be < 0)
-        const int c3 = (a2c0 >> 1) - C + lane;                // (arithmetic shift: floor)
-        const int c3w = wrapi(c3, Nc3);
-        v2f w3av[kInvR3Max], w3hd[kInvR3Max];
+        // the A parts of the level-(l+1) warm-up rows s2 = 0 .. H2-2: output (s2 + PHI) & 1 of level-(l+2) window (s2 + PHI) >> 1
+        static_for<H2 - 1>([&](auto S2) {
+            constexpr int s2 = decltype(S2)::value;
+            constexpr int t = (s2 + PHI) >> 1, idx3 = (s2 + PHI) & 1;
+            v2f av[H2], hd[H2];
 #pragma unroll
-        for (int r = 0; r < kInvR3Max; r++) {
-            const size_t o = (size_t)wrapi(P3a - C + min(r, nr3 - 1), Nr3) * Nc3 + c3w;
-            w3av[r] = v2f{b3.A3[o], b3.V3[o]};
-            w3hd[r] = v2f{b3.H3[o], b3.D3[o]};
-        }
-        const int colbase = 2 * c3 - a2c0;  // LDS column of the lane's first A_{l+1} column
-        const bool lane_ok = (lane >= C) && (lane < 64 - C);
-        static_for<kInvR3Max - H2 + 1>([&](auto PI) {
-            constexpr int pi = decltype(PI)::value;
-            if (pi < np) {
-                v2f av[H2], hd[H2];
-#pragma unroll
-                for (int j = 0; j < H2; j++) {
-                    av[j] = w3av[pi + j];
-                    hd[j] = w3hd[pi + j];
-                }
-#pragma unroll
-                for (int idx = 0; idx < 2; idx++) {
-                    float a0, a1;
-                    if (idx == 0) synth_pair(av, hd, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, a0, a1);
-                    else synth_pair(av, hd, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, a0, a1);
-                    const int s2 = 2 * (P3a + pi) - SHIFT + idx - Q0;  // stream row of this A_{l+1} row
-                    if (s2 >= 0 && s2 < nA2 && lane_ok) {
-                        if (colbase >= 0 && colbase < 64) lds_a2[s2 * 64 + colbase] = a0;
-                        if (colbase + 1 >= 0 && colbase + 1 < 64) lds_a2[s2 * 64 + colbase + 1] = a1;
-                    }
-                }
+            for (int j = 0; j < H2; j++) {
+                av[j] = w3av[t + j];
+                hd[j] = w3hd[t + j];
             }
+            r2av[s2].x = a2_from(av, hd, std::integral_constant<int, 1 - idx3>{});
         });
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    }
-    auto a2_lds = [&](int s2) { return lds_a2[min(s2, kInvA2Rows - 1) * 64 + lane]; };
-    CASC_TRACE(1);  // three-level prologue done (two-level form: nothing happened yet)
-
-    if constexpr (L3) {
-        // the A parts of the level-(l+1) ring rows and row registers, now that the private rows exist
+        // the ring holds the window of step T0 - 1: loop step 0 rotates it and inserts q3
 #pragma unroll
-        for (int r = 0; r < H2 - 1; r++) r2av[r].x = a2_lds(r);
-        q2[0] = a2_lds(H2 - 1);
+        for (int j = 0; j < H2; j++) {
+            r3av[j] = w3av[T0 - 1 + j];
+            r3hd[j] = w3hd[T0 - 1 + j];
+        }
     }
+    CASC_TRACE(1);  // warm-up syntheses done
     // hand over the level-(l+1) ring warm-up rows: the wave above completes its last H2-1 windows with them
     if (kw > 0) {
 #pragma unroll
@@ -321,16 +314,39 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
 
     auto step = [&](auto Pp, int sb) {
         constexpr int p = decltype(Pp)::value;
+        constexpr bool even = (p & 1) == 0;  // (H2 is even: the parity of the step is the parity of p)
+        constexpr int EX = even ? 4 : 0;     // VMEM instructions an even step issues before everything else
         const int s = sb * H2 + p;
         const bool l2act = last || (s < nQ);  // the level-(l+1) part runs (afterwards: level-l rows from the hand-off only)
         if (l2act) {
-            // ---- level l+1: coefficient row s2 = H2-1+s completes the window that starts at stream row s ----
-            const int s2 = H2 - 1 + s;
+            const int s2 = H2 - 1 + s;  // the level-(l+1) stream row that completes the window starting at stream row s
+            // ---- level l+2: every second step the ring advances by the row that was loaded two steps ago ----
+            if constexpr (even) {
+                asm_wait4<2 * kStep>(q3[0], q3[1], q3[2], q3[3]);
+#pragma unroll
+                for (int j = 0; j < H2 - 1; j++) {
+                    r3av[j] = r3av[j + 1];
+                    r3hd[j] = r3hd[j + 1];
+                }
+                r3av[H2 - 1] = v2f{asm_copy(q3[0]), asm_copy(q3[2])};
+                r3hd[H2 - 1] = v2f{asm_copy(q3[1]), asm_copy(q3[3])};
+                {
+                    // the row the even step after this one inserts: stream row T0 + s/2 + H2 (clamped to the last one needed)
+                    const size_t o = off3(min(T0 + (s >> 1) + H2, last3));
+                    asm_load_s(q3[0], b3.A3 + o, voff3);
+                    asm_load_s(q3[1], b3.H3 + o, voff3);
+                    asm_load_s(q3[2], b3.V3 + o, voff3);
+                    asm_load_s(q3[3], b3.D3 + o, voff3);
+                }
+            }
+            // the A part of stream row s2: first (even step: tap parity 1) or second output of the current level-(l+2) window
+            const float a2 = a2_from(r3av, r3hd, std::integral_constant<int, even ? 1 : 0>{});
+            // ---- level l+1 ----
             constexpr int sl = (H2 - 1 + p) % H2;
             // (no control flow between a counted wait and the re-issue of its registers: the wait, the copies out of the row
             // registers and the next loads always run; WHICH value enters the ring is a select on finished values)
-            asm_wait4<kWait2>(q2[0], q2[1], q2[2], q2[3]);
-            v4f e = v4f{asm_copy(q2[0]), asm_copy(q2[2]), asm_copy(q2[1]), asm_copy(q2[3])};
+            asm_wait3<2 * (3 + 2) + EX>(q2[1], q2[2], q2[3]);
+            v4f e = v4f{a2, asm_copy(q2[2]), asm_copy(q2[1]), asm_copy(q2[3])};
             if (!(last || s2 < nQ)) {  // ... from the wave below (its ring warm-up rows)
                 if (flags) casc_flag_wait(lds_flags + kw + 1, 1);
                 e = *lds_l2(lds_rd, s2 - nQ);
@@ -339,8 +355,6 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
             r2hd[sl] = v2f{e.z, e.w};
             {
                 const size_t o = off2(min(s2 + 1, last2));  // the row needed one step ahead (clamped to the last one the wave loads)
-                if constexpr (L3) q2[0] = a2_lds(min(s2 + 1, last2));
-                else asm_load_s(q2[0], b.A2 + o, voff2);
                 asm_load_s(q2[1], b.H2 + o, voff2);
                 asm_load_s(q2[2], b.V2 + o, voff2);
                 asm_load_s(q2[3], b.D2 + o, voff2);
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
                 float a0, a1;
                 synth_pair(r2av, r2hd, std::integral_constant<int, p % H2>{}, std::integral_constant<int, 1 - idx>{}, a0, a1);
                 // ---- level l: stream row r1 enters the ring with its H,V,D row ----
-                asm_wait3<kWait1>(q1[idx][0], q1[idx][1], q1[idx][2]);
+                asm_wait3<2 + (3 + 2) + 3 + EX>(q1[idx][0], q1[idx][1], q1[idx][2]);
                 ra[sl] = v2f{a0, a1};
                 rh[sl] = asm_copy(q1[idx][0]);
                 rv[sl] = asm_copy(q1[idx][1]);
@@ -392,7 +406,10 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
         });
     };
 
-    asm_drain1(q2[0]);
+    asm_drain1(q3[0]);
+    asm_drain1(q3[1]);
+    asm_drain1(q3[2]);
+    asm_drain1(q3[3]);
     asm_drain1(q2[1]);
     asm_drain1(q2[2]);
     asm_drain1(q2[3]);
@@ -402,16 +419,16 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
         asm_drain1(q1[k][1]);
         asm_drain1(q1[k][2]);
     });
-    CASC_TRACE(2);  // ring warm-up rows and first row registers landed
+    CASC_TRACE(2);  // first row registers landed
     for (int sb = 0;; sb++) {
         bool fin = false;
         static_for<H2>([&](auto Pp) {
             constexpr int p = decltype(Pp)::value;
             if (!fin) {
                 step(Pp, sb);
-                // hand-off order: level-(l+1) rows are written in the prologue and first read at step nQ-(H2-1) >= 1, level-l
-                // rows are written during steps 0 .. XS-1 and first read at step nQ >= XS: one barrier after each of the first
-                // XS steps (every wave runs them: nsteps > XS).  LDS only -- the global loads in flight are not drained.
+                // hand-off order without flags: level-(l+1) rows are written in the prologue and first read at step nQ-(H2-1) >= 1,
+                // level-l rows are written during steps 0 .. XS-1 and first read at step nQ >= XS: one barrier after each of the
+                // first XS steps (every wave runs them: nsteps > XS).  LDS only -- the global loads in flight are not drained.
                 if constexpr (p < XS || p == 0) {
                     if (sb == 0 && !flags) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 }
@@ -425,6 +442,10 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
         if (fin) break;
     }
     CASC_TRACE(5);  // loop left
+    asm_drain1(q3[0]);
+    asm_drain1(q3[1]);
+    asm_drain1(q3[2]);
+    asm_drain1(q3[3]);
     asm_drain1(q2[1]);
     asm_drain1(q2[2]);
     asm_drain1(q2[3]);
@@ -444,43 +465,33 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
 #define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
 
 template <int HLEN>
-static int launch_inv_cascw(const CascInvBands& b, const CascInv3* b3, float* out, float* trash, int nr, int nc, const Taps2<float>& f)
+static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* out, float* trash, int nr, int nc, const Taps2<float>& f)
 {
     using G = CascInvGeom<HLEN>;
     constexpr int H2 = G::H2, XS = H2 / 2;
-    const int nc1 = nc / 2, nr2 = nr / 4;
+    const int nc1 = nc / 2, np = nr / 8;  // level-(l+1) row PAIRS
     const int strips = idiv_up(nc1, G::MAXVL * 2);
     const int VL = idiv_up(nc1 / 2, strips);
     int Wk = knob(KN_CASC_IWG);
-    if (Wk != 4 && Wk != 8 && Wk != 16) Wk = 8;
-    constexpr size_t REG = casc_inv_region_bytes<HLEN>();
-    const bool l3 = b3 != nullptr;
-    auto lds_bytes = [&](int w) { return (size_t)(w - 1) * REG + (l3 ? (size_t)w * kInvA2Rows * 256 : 0) + 64 * sizeof(int); };
+    if (Wk != 4 && Wk != 8 && Wk != 16) Wk = 16;
+    constexpr size_t REG = casc_inv3_region_bytes<HLEN>();
+    auto lds_bytes = [&](int w) { return (size_t)(w - 1) * REG + 64 * sizeof(int); };
     const int wgs = knob(KN_CASC_IWAVES) > 0 ? idiv_up(knob(KN_CASC_IWAVES), Wk) : 256;  // default: one workgroup per CU
-    // the kernel's split of R level-(l+1) rows over W waves, replayed: rows of the largest middle wave and of the last wave
-    auto split = [&](int R, int w, int* mid, int* lastw) {
-        const int E = std::min(XS, R / w - 1);
-        const int base = (R + E) / w, rem = (R + E) % w;
-        *mid = base + (rem > 0 ? 1 : 0);
-        *lastw = R - ((w - 1) * base + std::min(w - 1, rem));
-    };
-    // (W, gy) fits when every wave gets >= H2 rows and, in the three-level form, no wave needs more than kInvA2Rows private
-    // A_{l+1} rows (a middle wave: its own rows; the last one: + the recomputed halo) or kInvR3Max level-(l+2) rows
+    // (W, gy) fits when every wave but the last gets >= H2 rows (the hand-off is first read at step nQ-(H2-1) >= 1) and the last
+    // one at least one pair; the kernel's split, replayed on the two chunk sizes that occur
     auto fits = [&](int w, int g) {
         if (lds_bytes(w) > 150 * 1024) return false;
-        for (int R : {nr2 / g, idiv_up(nr2, g)}) {
-            if (R / w < H2) return false;
-            if (l3) {
-                int mid, lw;
-                split(R, w, &mid, &lw);
-                const int na2 = std::max(mid, lw + H2 - 1 + XS);
-                if (na2 > kInvA2Rows || (na2 + 1) / 2 + 1 + H2 - 1 > kInvR3Max) return false;
-            }
+        for (int Rp : {np / g, idiv_up(np, g)}) {
+            const int Ep = std::min(std::max(XS / 2, 1), std::max(Rp / w - 1, 0));
+            const int basep = (Rp + Ep) / w, remp = (Rp + Ep) % w;
+            if (2 * basep < H2) return false;
+            const int lastp = Rp - ((w - 1) * basep + std::min(w - 1, remp));
+            if (lastp < 1) return false;
         }
         return true;
     };
     int W = 0, gy = 0;
-    for (int w : {Wk, 8, 16, 4}) {
+    for (int w : {Wk, 16, 8, 4}) {
         for (int g = std::max(1, wgs / strips); g >= std::max(1, wgs / strips / 2) && !W; g--)
             if (fits(w, g)) {
                 W = w;
@@ -494,49 +505,31 @@ static int launch_inv_cascw(const CascInvBands& b, const CascInv3* b3, float* ou
     const dim3 grid((unsigned)(8 * cm.cpx));
     size_t lds = lds_bytes(W);
     if (knob(KN_CASC_LDSPAD) > 0) lds = std::max(lds, (size_t)knob(KN_CASC_LDSPAD) * 1024);  // (tuning: see launch_fwd_casc)
-    void (*k)(CascInvBands, CascInv3, float*, int, int, int, float*, CascMap, Taps2<float>);
-    if (l3) k = (W == 4) ? k_inv2d_cascw<HLEN, 4, true> : (W == 8) ? k_inv2d_cascw<HLEN, 8, true> : k_inv2d_cascw<HLEN, 16, true>;
-    else k = (W == 4) ? k_inv2d_cascw<HLEN, 4, false> : (W == 8) ? k_inv2d_cascw<HLEN, 8, false> : k_inv2d_cascw<HLEN, 16, false>;
+    void (*k)(CascInvBands, CascInv3B, float*, int, int, int, float*, CascMap, Taps2<float>);
+    k = (W == 4) ? k_inv2d_casc3<HLEN, 4> : (W == 8) ? k_inv2d_casc3<HLEN, 8> : k_inv2d_casc3<HLEN, 16>;
     if (lds > 64 * 1024) {  // opt-in once per (kernel, device), not per launch
-        int rc;
-        if (l3) rc = (W == 4) ? lds_opt_in<k_inv2d_cascw<HLEN, 4, true>>() : (W == 8) ? lds_opt_in<k_inv2d_cascw<HLEN, 8, true>>() : lds_opt_in<k_inv2d_cascw<HLEN, 16, true>>();
-        else rc = (W == 4) ? lds_opt_in<k_inv2d_cascw<HLEN, 4, false>>() : (W == 8) ? lds_opt_in<k_inv2d_cascw<HLEN, 8, false>>() : lds_opt_in<k_inv2d_cascw<HLEN, 16, false>>();
+        const int rc = (W == 4) ? lds_opt_in<k_inv2d_casc3<HLEN, 4>>() : (W == 8) ? lds_opt_in<k_inv2d_casc3<HLEN, 8>>() : lds_opt_in<k_inv2d_casc3<HLEN, 16>>();
         if (rc != PDWT_OK) return rc;
     }
-    const CascInv3 z3 = l3 ? *b3 : CascInv3{nullptr, nullptr, nullptr, nullptr};
     KTimer kt(K_INV2D_CASC, true);
-    PDWT_LAUNCH_KT(kt, k, grid, dim3(64 * W), lds, b, z3, out, nr, nc, VL, trash, cm, f);
+    PDWT_LAUNCH_KT(kt, k, grid, dim3(64 * W), lds, b, b3, out, nr, nc, VL, trash, cm, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
 
-#define PDWT_CASCW_INV_HLENS(X) X(4) X(6) X(8) X(10)
-
-// A3 != NULL: three levels (A2 is not read: it is synthesised from the level-(l+2) bands on the fly)
-int inv2d_cascw_f32(const float* A2, const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1,
-                    const float* A3, const float* H3, const float* V3, const float* D3, float* out, float* trash, int nr, int nc, int hlen,
-                    const Taps2<float>& f)
+// Three levels, all streamed.  PDWT_OK when launched, 1 when the geometry / filter length is outside this path (the caller falls
+// back to the prologue form of dwt_casc_invw.hip).
+int inv2d_casc3_f32(const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1, const float* A3,
+                    const float* H3, const float* V3, const float* D3, float* out, float* trash, int nr, int nc, int hlen, const Taps2<float>& f)
 {
-    if (knob(KN_CASC) != 1 || knob(KN_CASC_IWG) == 1 || !stream_enabled() || !trash) return 1;
-    const bool l3 = A3 != nullptr;
-    if (l3 && knob(KN_CASC_L3) != 1 && knob(KN_CASC_L3) != 2) return 1;
-    if (l3 && knob(KN_CASC_L3) == 1 && !(knob(KN_CASC_MIN) > (long long)nr * nc)) {
-        // all three levels streamed (dwt_casc_inv3.hip); this file's prologue form takes what that one does not (casc_l3 = 2 forces it)
-        const int rc = inv2d_casc3_f32(H2, V2, D2, H1, V1, D1, A3, H3, V3, D3, out, trash, nr, nc, hlen, f);
-        if (rc <= 0) return rc;
-    }
-    const int m = l3 ? 7 : 3;
-    if ((nr & m) || (nc & m) || nc < 256 || nr < 32 * hlen) return 1;
-    if ((long long)nr * nc < (long long)knob(KN_CASC_MIN)) return 1;
+    if (knob(KN_CASC_L3) != 1) return 1;  // (2 = the prologue form)
+    if ((nr & 7) || (nc & 7) || nc < 256 || nr < 32 * hlen) return 1;
     if (!al16(out) || !al16(H1) || !al16(V1) || !al16(D1) || !al16(H2) || !al16(V2) || !al16(D2) || !al16(trash)) return 1;
-    if (!l3 && !al16(A2)) return 1;
-    const CascInvBands b = {A2, H2, V2, D2, H1, V1, D1};
-    const CascInv3 b3 = {A3, H3, V3, D3};
+    const CascInvBands b = {nullptr, H2, V2, D2, H1, V1, D1};
+    const CascInv3B b3 = {A3, H3, V3, D3};
     switch (hlen) {
-#define X(H) \
-    case H: return launch_inv_cascw<H>(b, l3 ? &b3 : nullptr, out, trash, nr, nc, f);
-        PDWT_CASCW_INV_HLENS(X)
-#undef X
+        case 4: return launch_inv_casc3<4>(b, b3, out, trash, nr, nc, f);
+        case 8: return launch_inv_casc3<8>(b, b3, out, trash, nr, nc, f);
         default: return 1;
     }
 }
