@@ -22,6 +22,7 @@ struct CascMap {
     int gy;      // W > 1: workgroup-chunk rows (gy * strips workgroups in all)
     int stag;    // W > 1: hand-off ordered by LDS flags instead of barriers (free-running waves) when != 0; |stag| - 1 = start
                  // skew between the four wave groups of a SIMD in units of 512 cycles (> 0: the bottom waves start first)
+    int prio;    // W > 1: rotate the issue priority of the waves that share a SIMD (s_setprio per step)
 };
 
 // ---- LDS flags of the workgroup cascade kernels (free-running waves) --------------------------------------------------

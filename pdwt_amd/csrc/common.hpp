@@ -107,6 +107,7 @@ enum KnobId {
     KN_CASC_L3,            // third level folded into the inverse cascade launch: 1 = streamed (dwt_casc_inv3.hip) where it applies, 2 = prologue form only, 0 = never
     KN_CASC_STAG,          // forward workgroup cascade: 0 = barriers order the LDS hand-off; != 0 = LDS flags (free-running waves), |v| - 1 = start skew per wave group (512-cycle units; > 0 bottom waves first)
     KN_CASC_ISTAG,         // inverse workgroup cascade: the same
+    KN_CASC_IPRIO,         // inverse workgroup cascade (dwt_casc_inv3.hip): rotate the issue priority of the waves of a SIMD per step
     KN_CASC_LDSPAD,        // workgroup cascades: request at least this many KB of LDS per workgroup (occupancy experiments)
     KN_STREAM,             // 0: LDS-tiled fused level kernels instead of the streaming ones
     KN_STREAM_R,           // streaming level kernels: rows per wave (0 = auto)

@@ -655,7 +655,7 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
         while (gy > 1 && (nr4 / gy) / W < HLEN / 2) gy--;  // every wave needs >= HLEN/2 level-2 rows (see the kernel)
         if (gy >= 1 && (nr4 / gy) / W >= HLEN / 2) {
             const int nwg = gy * strips;
-            const CascMap cm = {idiv_up(nwg, 8), strips, gy, knob(KN_CASC_STAG)};
+            const CascMap cm = {idiv_up(nwg, 8), strips, gy, knob(KN_CASC_STAG), 0};
             const dim3 grid((unsigned)(8 * cm.cpx));
             size_t lds = (size_t)(W - 1) * REG + 64 * sizeof(int);  // hand-off regions + flag words
             // (tuning: a larger LDS request lowers the workgroups per CU, i.e. turns a resident grid into an oversubscribed one)
@@ -679,7 +679,7 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
     int cpx = (knob(KN_CASC_WAVES) > 0 ? knob(KN_CASC_WAVES) : 1024) / (8 * strips);
     if (cpx > nr / 4 / 4 / 8) cpx = nr / 4 / 4 / 8;
     if (cpx < 1) cpx = 1;
-    const CascMap cm = {cpx, strips, 0, 0};
+    const CascMap cm = {cpx, strips, 0, 0, 0};
     const dim3 grid((unsigned)(8 * idiv_up(cpx * strips, 4)));
     // row registers in flight (= prefetch distance): HLEN/2 measured best (26.2 us vs 26.8 @HLEN, 28.5 @2*HLEN for 4096^2 db4);
     // a shorter pipeline fills and drains faster, and every wave fills and drains at the same time
@@ -723,7 +723,7 @@ static int launch_inv_casc(const CascInvBands& b, float* out, float* trash, int 
     int cpx = (knob(KN_CASC_IWAVES) > 0 ? knob(KN_CASC_IWAVES) : 2048) / (8 * strips);
     if (cpx > nr / 2 / 8 / 8) cpx = nr / 2 / 8 / 8;  // at least 8 level-l coefficient rows per chunk
     if (cpx < 1) cpx = 1;
-    const CascMap cm = {cpx, strips, 0, 0};
+    const CascMap cm = {cpx, strips, 0, 0, 0};
     const dim3 grid((unsigned)(8 * idiv_up(cpx * strips, 4)));
     KTimer kt(K_INV2D_CASC, true);
     constexpr int H2 = HLEN / 2;

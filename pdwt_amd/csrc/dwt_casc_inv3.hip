@@ -64,8 +64,9 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     const int Np = Nr2 >> 1;
     const int Jp = (int)(((long long)gy * Np) / cm.gy);
     const int Rp = (int)(((long long)(gy + 1) * Np) / cm.gy) - Jp;
-    // the last wave runs XS steps more than it owns rows (the recomputed halo): it gets XS rows (XS / 2 pairs, at least one) fewer
-    const int Ep = min(max(XS / 2, 1), max(Rp / W - 1, 0));
+    // every wave runs nQ + XS steps (the last XS of the last wave are full steps: it recomputes its halo; the others only run the
+    // level-l part on rows from the hand-off), so an even split of the pairs is the balanced one (timeline: r03_c2_timeline.md)
+    const int Ep = 0;
     const int basep = (Rp + Ep) / W, remp = (Rp + Ep) % W;
     const int startp = kw * basep + min(kw, remp);
     const bool last = (kw == W - 1);
@@ -85,10 +86,11 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     const bool valid = (lane >= NBT) && (lane < NBT + VL) && (cx1 < Nc1);
     const int cx1w = wrapi(cx1, Nc1);
     const int cx2w = cx1w >> 1;
-    // level l+2: lane <-> column c3 = (X0 >> 1) - C + lane; its two A_{l+1} columns are 2 c3, 2 c3 + 1.  The lane of the main
-    // mapping that holds A_{l+1} column X = X0 + lane takes it from level-(l+2) lane (X >> 1) - (X0 >> 1) + C, output X & 1.
-    const int c3w = wrapi((X0 >> 1) - C + lane, Nc3);
-    const int bp_addr = 4 * (((X0 + lane) >> 1) - (X0 >> 1) + C);
+    // level l+2: lane <-> column c3 = ((X0 + 1) >> 1) - C + lane, which produces the natural pair (A[2 c3 - 1], A[2 c3]).  The lane
+    // of the main mapping that holds A_{l+1} column X = X0 + lane takes it from level-(l+2) lane ((X + 1) >> 1) - ((X0 + 1) >> 1) + C:
+    // the second output when X is even, the first when it is odd.
+    const int c3w = wrapi(((X0 + 1) >> 1) - C + lane, Nc3);
+    const int bp_addr = 4 * (((X0 + lane + 1) >> 1) - ((X0 + 1) >> 1) + C);
     const bool bp_odd = ((X0 + lane) & 1) != 0;
 
     auto off3 = [&](int i) { return (size_t)wrapi(P3_0 - C + i, Nr3) * Nc3; };
@@ -120,53 +122,67 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
 #pragma unroll
     for (int k = 0; k < H2; k++) ra[k] = rh[k] = rv[k] = rd[k] = v2f{0.f, 0.f};
 
-    // two adjacent outputs (the columns 2c, 2c+1 of a lane that holds coefficient column c) of one synthesis level from the ring
-    // window av / hd starting at slot S0 with tap parity OFF: column synthesis -> DPP halo of (t1, t2) -> row synthesis
-    auto synth_pair = [&](const v2f (&av)[H2], const v2f (&hd)[H2], auto S0, auto OFF, float& a0, float& a1) {
+    // Row synthesis on NATURAL pairs.  With SHIFT = 1 window position p (t columns p-C .. p-C+H2-1) yields the outputs 2p-1 and 2p,
+    // and the two share every product's t operand: (o[2p-1], o[2p]) += splat(t[p-C+j]) * (F[m-1], F[m]), m = HLEN-1-2j -- one
+    // v_pk_fma_f32 per tap with the taps as an aligned SGPR pair.  The kernels of dwt_casc_invw.hip compute the pairs a lane OWNS
+    // (2c, 2c+1), which straddle two windows: scalar FMA chains that hipcc then re-packs with a v_mov per operand.  Here a lane
+    // computes natural pairs only and the neighbour's half travels by one DPP move.  Same products, same order per output.
+    static_assert(SHIFT == 1, "even H2");
+    // the taps live once, as aligned SGPR pairs (F[2i], F[2i+1]): the row passes use a pair as it is, the column passes broadcast
+    // one half of it (pk_fma_sbcast, stream_dev.hpp)
+    v2f fa2[H2], fb2[H2];
+#pragma unroll
+    for (int i = 0; i < H2; i++) {
+        fa2[i] = v2f{f.a[2 * i], f.a[2 * i + 1]};
+        fb2[i] = v2f{f.b[2 * i], f.b[2 * i + 1]};
+    }
+    auto nat_pair = [&](const float* t1w, const float* t2w) {  // t?w[j] = t[p-C+j]
+        v2f s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < H2; j++) {
+            const int m = HLEN - 1 - 2 * j;  // taps (F[m-1], F[m]) = pair (m-1)/2
+            s1 = pk_fma(splat(t1w[j]), fa2[(m - 1) / 2], s1);
+            s2 = pk_fma(splat(t2w[j]), fb2[(m - 1) / 2], s2);
+        }
+        return s1 + s2;
+    };
+    // one synthesis level on a lane that holds ONE coefficient column c: the natural pair (A[2c-1], A[2c]) of window p = c from the
+    // ring window av / hd starting at slot S0 with tap parity OFF (column synthesis -> DPP halo of (t1, t2) -> row synthesis)
+    auto synth_col = [&](const v2f (&av)[H2], const v2f (&hd)[H2], auto S0, auto OFF) {
         constexpr int s0 = decltype(S0)::value, off = decltype(OFF)::value;
         v2f sav = {0.f, 0.f}, shd = {0.f, 0.f};
         static_for<H2>([&](auto J) {
             constexpr int j = decltype(J)::value;
-            constexpr int s = (s0 + j) % H2;
+            constexpr int sl = (s0 + j) % H2;
             constexpr int k = HLEN - 1 - (2 * j + off);
-            sav = pk_fma(av[s], splat(f.a[k]), sav);
-            shd = pk_fma(hd[s], splat(f.b[k]), shd);
+            sav = pk_fma_sbcast<k & 1, j == 0>(av[sl], fa2[k >> 1], sav);
+            shd = pk_fma_sbcast<k & 1, j == 0>(hd[sl], fb2[k >> 1], shd);
         });
         const v2f t = sav + shd;  // (t1, t2) of the lane's column
-        float t1[WIN2], t2[WIN2];
-        t1[NB2] = t.x;
-        t2[NB2] = t.y;
+        float t1w[H2], t2w[H2];   // window of p = c: columns c-C .. c-C+H2-1
+        t1w[C] = t.x;
+        t2w[C] = t.y;
 #pragma unroll
-        for (int k = 0; k < NB2; k++) {
-            t1[NB2 - 1 - k] = dpp_shr1(t1[NB2 - k]);
-            t2[NB2 - 1 - k] = dpp_shr1(t2[NB2 - k]);
-            t1[NB2 + 1 + k] = dpp_shl1(t1[NB2 + k]);
-            t2[NB2 + 1 + k] = dpp_shl1(t2[NB2 + k]);
+        for (int k = 1; k <= C; k++) {
+            t1w[C - k] = dpp_shr1(t1w[C - k + 1]);
+            t2w[C - k] = dpp_shr1(t2w[C - k + 1]);
         }
-        float o2[2];
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const int gp = e + SHIFT;
-            const int pl = gp >> 1, offx = 1 - (gp & 1);
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < H2; j++) {
-                const int k = HLEN - 1 - (2 * j + offx);
-                s1 = __builtin_fmaf(t1[NB2 + pl - C + j], f.a[k], s1);
-                s2 = __builtin_fmaf(t2[NB2 + pl - C + j], f.b[k], s2);
-            }
-            o2[e] = s1 + s2;
+        for (int k = 1; k <= H2 - 1 - C; k++) {
+            t1w[C + k] = dpp_shl1(t1w[C + k - 1]);
+            t2w[C + k] = dpp_shl1(t2w[C + k - 1]);
         }
-        a0 = o2[0];
-        a1 = o2[1];
+        return nat_pair(t1w, t2w);
     };
-    // one A_{l+1} value per lane of the main mapping from a level-(l+2) window
+    // the lane's two columns (2c, 2c+1) of the level below: its own second output and the first output of the lane to the right
+    auto own_pair = [&](v2f p0) { return v2f{p0.y, dpp_shl1(p0.x)}; };
+    // one A_{l+1} value per lane of the main mapping from a level-(l+2) window: column X is the second output of level-(l+2)
+    // column X/2 when X is even and the first output of column (X+1)/2 when it is odd
     auto a2_from = [&](const v2f (&av)[H2], const v2f (&hd)[H2], auto OFF) {
-        float a0, a1;
-        synth_pair(av, hd, std::integral_constant<int, 0>{}, OFF, a0, a1);
-        const int g0 = __builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(a0));
-        const int g1 = __builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(a1));
-        return __int_as_float(bp_odd ? g1 : g0);
+        const v2f p0 = synth_col(av, hd, std::integral_constant<int, 0>{}, OFF);
+        const int glo = __builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(p0.x));
+        const int ghi = __builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(p0.y));
+        return __int_as_float(bp_odd ? glo : ghi);
     };
 
     // ---- ring warm-up rows of all three levels and the first row registers, issued together ----------------------------
@@ -238,78 +254,49 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
 
     float* const tr = trash + (size_t)(blockIdx.x & 7) * Nc;  // a trash ROW (the dispatcher checks the area holds 8 of them)
 
-    // one output row of level l from the ring window starting at slot S0 with tap parity OFF (cf. k_inv2d_stream::emit)
+    // one output row of level l from the ring window starting at slot S0 with tap parity OFF: the lane holds the coefficient columns
+    // (c0, c0+1) and owns the outputs 2 c0 .. 2 c0 + 3 = second output of window p = c0 (computed by the lane to the LEFT as the
+    // second half of its last pair), the natural pair of p = c0+1, first output of p = c0+2
     auto emit = [&](auto S0, auto OFF, bool own, int g) {
         constexpr int s0 = decltype(S0)::value, off = decltype(OFF)::value;
         // rows of the ring warm-up / beyond the wave's windows: the store is still issued (to a trash row, the VMEM count must
         // not change) but the arithmetic is skipped -- a uniform branch
-        float o4[4] = {0.f, 0.f, 0.f, 0.f};
+        v4f o4;
+        asm("" : "=v"(o4));  // (a row that goes to the trash carries whatever these registers hold: no instruction spent on it)
         if (own) {
             v2f sa = {0.f, 0.f}, sh = {0.f, 0.f}, sv = {0.f, 0.f}, sd = {0.f, 0.f};
             static_for<H2>([&](auto J) {
                 constexpr int j = decltype(J)::value;
-                constexpr int s = (s0 + j) % H2;
+                constexpr int sl = (s0 + j) % H2;
                 constexpr int k = HLEN - 1 - (2 * j + off);
-                const v2f fl = splat(f.a[k]), fh = splat(f.b[k]);
-                sa = pk_fma(ra[s], fl, sa);
-                sh = pk_fma(rh[s], fh, sh);
-                sv = pk_fma(rv[s], fl, sv);
-                sd = pk_fma(rd[s], fh, sd);
+                sa = pk_fma_sbcast<k & 1, j == 0>(ra[sl], fa2[k >> 1], sa);
+                sh = pk_fma_sbcast<k & 1, j == 0>(rh[sl], fb2[k >> 1], sh);
+                sv = pk_fma_sbcast<k & 1, j == 0>(rv[sl], fa2[k >> 1], sv);
+                sd = pk_fma_sbcast<k & 1, j == 0>(rd[sl], fb2[k >> 1], sd);
             });
             const v2f t1o = sa + sh, t2o = sv + sd;
-            float t1[WIN1], t2[WIN1];
-            t1[NB1 * 2] = t1o.x;
-            t1[NB1 * 2 + 1] = t1o.y;
-            t2[NB1 * 2] = t2o.x;
-            t2[NB1 * 2 + 1] = t2o.y;
+            // t columns c0 + 1 - C .. c0 + 2 - C + H2 - 1 (both windows), index 0 = column c0 + 1 - C; the lane's own two sit at C-1, C
+            constexpr int NT = H2 + 1;
+            float t1w[NT], t2w[NT];
+            t1w[C - 1] = t1o.x;
+            t1w[C] = t1o.y;
+            t2w[C - 1] = t2o.x;
+            t2w[C] = t2o.y;
 #pragma unroll
-            for (int k = 0; k < NB1; k++) {
-                const int dl = (NB1 - 1 - k) * 2, sl = (NB1 - k) * 2, dr = (NB1 + 1 + k) * 2, sr = (NB1 + k) * 2;
-#pragma unroll
-                for (int cc = 0; cc < 2; cc++) {
-                    t1[dl + cc] = dpp_shr1(t1[sl + cc]);
-                    t2[dl + cc] = dpp_shr1(t2[sl + cc]);
-                    t1[dr + cc] = dpp_shl1(t1[sr + cc]);
-                    t2[dr + cc] = dpp_shl1(t2[sr + cc]);
-                }
+            for (int i = C - 2; i >= 0; i--) {  // from the lane to the left (two columns per lane)
+                t1w[i] = dpp_shr1(t1w[i + 2]);
+                t2w[i] = dpp_shr1(t2w[i + 2]);
             }
-            auto pair_out = [&](auto E0) {
-                constexpr int e0 = decltype(E0)::value;
-                constexpr int pl = (e0 + SHIFT) >> 1;
-                v2f s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < H2; j++) {
-                    const int m = HLEN - 1 - 2 * j;
-                    s1 = pk_fma(splat(t1[NB1 * 2 + pl - C + j]), v2f{f.a[m - 1], f.a[m]}, s1);
-                    s2 = pk_fma(splat(t2[NB1 * 2 + pl - C + j]), v2f{f.b[m - 1], f.b[m]}, s2);
-                }
-                const v2f o = s1 + s2;
-                o4[e0] = o.x;
-                o4[e0 + 1] = o.y;
-            };
-            auto single_out = [&](auto Ee) {
-                constexpr int eo = decltype(Ee)::value;
-                constexpr int gp = eo + SHIFT;
-                constexpr int pl = gp >> 1, offx = 1 - (gp & 1);
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int j = 0; j < H2; j++) {
-                    const int k = HLEN - 1 - (2 * j + offx);
-                    s1 = __builtin_fmaf(t1[NB1 * 2 + pl - C + j], f.a[k], s1);
-                    s2 = __builtin_fmaf(t2[NB1 * 2 + pl - C + j], f.b[k], s2);
-                }
-                o4[eo] = s1 + s2;
-            };
-            if constexpr (SHIFT == 0) {
-                pair_out(std::integral_constant<int, 0>{});
-                pair_out(std::integral_constant<int, 2>{});
-            } else {
-                single_out(std::integral_constant<int, 0>{});
-                pair_out(std::integral_constant<int, 1>{});
-                single_out(std::integral_constant<int, 3>{});
+            for (int i = C + 1; i < NT; i++) {  // from the lane to the right
+                t1w[i] = dpp_shl1(t1w[i - 2]);
+                t2w[i] = dpp_shl1(t2w[i - 2]);
             }
+            const v2f pa = nat_pair(t1w, t2w);          // outputs 2 c0 + 1, 2 c0 + 2
+            const v2f pb = nat_pair(t1w + 1, t2w + 1);  // outputs 2 c0 + 3, 2 c0 + 4 (the second belongs to the lane to the right)
+            o4 = v4f{dpp_shr1(pb.y), pa.x, pa.y, pb.x};
         }
-        asm_store_sm(own ? out + (size_t)wrap1(O0 + g, Nr) * Nc : tr, voffo, v4f{o4[0], o4[1], o4[2], o4[3]}, vmask);
+        asm_store_sm(own ? out + (size_t)wrap1(O0 + g, Nr) * Nc : tr, voffo, o4, vmask);
     };
 
     auto step = [&](auto Pp, int sb) {
@@ -318,6 +305,17 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
         constexpr int EX = even ? 4 : 0;     // VMEM instructions an even step issues before everything else
         const int s = sb * H2 + p;
         const bool l2act = last || (s < nQ);  // the level-(l+1) part runs (afterwards: level-l rows from the hand-off only)
+        if (cm.prio) {
+            // The issue arbiter prefers the OLDEST wave of a SIMD, so the waves that share a SIMD (kw, kw+4, ...) finish one after the
+            // other (timeline: the youngest ends 4 us after the oldest with the same rows).  Rotating a user priority with the step
+            // number gives every wave the same share.
+            switch ((s + (kw >> 2)) & 3) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
         if (l2act) {
             const int s2 = H2 - 1 + s;  // the level-(l+1) stream row that completes the window starting at stream row s
             // ---- level l+2: every second step the ring advances by the row that was loaded two steps ago ----
@@ -366,11 +364,10 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
             const int r1 = 2 * s + idx;
             constexpr int sl = q % H2;
             if (l2act) {
-                float a0, a1;
-                synth_pair(r2av, r2hd, std::integral_constant<int, p % H2>{}, std::integral_constant<int, 1 - idx>{}, a0, a1);
+                const v2f a01 = own_pair(synth_col(r2av, r2hd, std::integral_constant<int, p % H2>{}, std::integral_constant<int, 1 - idx>{}));
                 // ---- level l: stream row r1 enters the ring with its H,V,D row ----
                 asm_wait3<2 + (3 + 2) + 3 + EX>(q1[idx][0], q1[idx][1], q1[idx][2]);
-                ra[sl] = v2f{a0, a1};
+                ra[sl] = a01;
                 rh[sl] = asm_copy(q1[idx][0]);
                 rv[sl] = asm_copy(q1[idx][1]);
                 rd[sl] = asm_copy(q1[idx][2]);
@@ -482,7 +479,7 @@ static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* o
     auto fits = [&](int w, int g) {
         if (lds_bytes(w) > 150 * 1024) return false;
         for (int Rp : {np / g, idiv_up(np, g)}) {
-            const int Ep = std::min(std::max(XS / 2, 1), std::max(Rp / w - 1, 0));
+            const int Ep = 0;  // (the kernel's split)
             const int basep = (Rp + Ep) / w, remp = (Rp + Ep) % w;
             if (2 * basep < H2) return false;
             const int lastp = Rp - ((w - 1) * basep + std::min(w - 1, remp));
@@ -501,7 +498,7 @@ static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* o
     }
     if (!W) return 1;
     const int nwg = gy * strips;
-    const CascMap cm = {idiv_up(nwg, 8), strips, gy, knob(KN_CASC_ISTAG)};
+    const CascMap cm = {idiv_up(nwg, 8), strips, gy, knob(KN_CASC_ISTAG), knob(KN_CASC_IPRIO)};
     const dim3 grid((unsigned)(8 * cm.cpx));
     size_t lds = lds_bytes(W);
     if (knob(KN_CASC_LDSPAD) > 0) lds = std::max(lds, (size_t)knob(KN_CASC_LDSPAD) * 1024);  // (tuning: see launch_fwd_casc)

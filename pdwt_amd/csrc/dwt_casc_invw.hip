@@ -490,7 +490,7 @@ static int launch_inv_cascw(const CascInvBands& b, const CascInv3* b3, float* ou
     }
     if (!W) return 1;
     const int nwg = gy * strips;
-    const CascMap cm = {idiv_up(nwg, 8), strips, gy, knob(KN_CASC_ISTAG)};
+    const CascMap cm = {idiv_up(nwg, 8), strips, gy, knob(KN_CASC_ISTAG), 0};
     const dim3 grid((unsigned)(8 * cm.cpx));
     size_t lds = lds_bytes(W);
     if (knob(KN_CASC_LDSPAD) > 0) lds = std::max(lds, (size_t)knob(KN_CASC_LDSPAD) * 1024);  // (tuning: see launch_fwd_casc)

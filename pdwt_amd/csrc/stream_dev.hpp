@@ -52,6 +52,26 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat(float x) { return v2f{x, x}; }
 
+// acc += v * splat(one half of an SGPR pair).  v_pk_fma_f32 can feed either half of a 64-bit source to both lanes (op_sel /
+// op_sel_hi), also when the source is an SGPR pair (tools/probes/pkfma.hip) -- hipcc does not use that for scalar operands: it
+// materialises a pre-splatted SGPR pair (t, t) per tap, 2 SGPRs per tap on top of the natural pairs the row passes use, and the
+// inverse cascade kernels then spill ~50 SGPRs to VGPR lanes (a v_readlane per use).  With these the taps live ONCE, as the
+// aligned pairs (F[2i], F[2i+1]).  FIRST: the accumulator starts at 0 (same result as pk_fma(v, splat, {0, 0})).
+template <int HALF, bool FIRST>
+__device__ __forceinline__ v2f pk_fma_sbcast(v2f v, v2f spair, v2f acc)
+{
+    if constexpr (FIRST) {
+        v2f r;
+        if constexpr (HALF == 0) asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(v), "s"(spair));
+        else asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(v), "s"(spair));
+        return r;
+    } else {
+        if constexpr (HALF == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(v), "s"(spair));
+        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(v), "s"(spair));
+        return acc;
+    }
+}
+
 // forward taps as (L[k], H[k]) pairs, by value in the kernarg segment (-> SGPR pairs)
 struct TapsLH {
     v2f t[PDWT_MAX_FILTER_WIDTH];
