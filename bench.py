@@ -35,6 +35,10 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the 157.3 TFLOP/s FP32 vector peak of MI3
 CONFIGS = {
     "c2": dict(Nr=4096, Nc=4096, dtype="float32", wname="db4", levels=3, do_swt=0, ndim=2, extra=False, unit="Mpixels/s",
                desc="4096x4096 float32, db4, 3 levels, separable DWT fwd+inv (BASELINE.json configs[1])"),
+    # the headline workload on a BATCH of distinct images cycled per step: the single-image working set (~170 MB) lives in the 256 MiB
+    # Infinity Cache, a batch that rotates through > 1 GB is what streams through HBM (report both)
+    "c2_batch": dict(Nr=4096, Nc=4096, dtype="float32", wname="db4", levels=3, do_swt=0, ndim=2, extra=False, unit="Mpixels/s", batch=16,
+                     desc="16 distinct 4096x4096 float32 images per GPU cycled per step, db4, 3 levels, fwd+inv each (working set 16 x 268 MB: out of the Infinity Cache)"),
     "c3": dict(Nr=4096, Nc=4096, dtype="float32", wname="db7", levels=5, do_swt=1, ndim=2, extra=False, unit="Mpixels/s",
                desc="4096x4096 float32, db7, 5 levels, SWT fwd+inv (configs[2])"),
     "c4": dict(Nr=8192, Nc=8192, dtype="float32", wname="sym8", levels=4, do_swt=0, ndim=1, extra=False, unit="Msamples/s",
@@ -167,6 +171,19 @@ def pywt_timing(cfg, Nr, Nc):
         return None
 
 
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the kernel sources of the library: profiles/pmc_traffic.json keeps the value its counters were
+    collected at, so a static traffic figure that predates a kernel change is flagged (`traffic_stale`) instead of trusted."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "pdwt_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".inc", ".hpp")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pick_dominant(cfg, kernels, per_kernel_bytes, levels_eff):
     """Dominant kernel (largest time per step among those with an algorithmic byte count) -> (name, bytes per step)."""
     import numpy as np
@@ -222,8 +239,22 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
                                     shape=(cfg["Nr"], cfg["Nc"]), device_ptr=img.data_ptr())
     assert W.state == pdwt_amd_mod().W_INIT, "Wavelets creation failed"
     levels_eff = W.info.nlevels
+    nbatch = cfg.get("batch", 1)
+    Ws = [W]
+    for bi in range(1, nbatch):  # the other images of the batch: distinct data, private instances (image + bands + scratch each)
+        g.manual_seed(1234 + rank + 1000 * bi)
+        xi = torch.rand(cfg["Nr"], cfg["Nc"], device="cuda", dtype=tdt, generator=g) * 255.0
+        torch.cuda.synchronize()
+        Ws.append(pdwt_amd_mod().Wavelets(None, cfg["wname"], cfg["levels"], do_swt=cfg["do_swt"], ndim=cfg["ndim"], dtype=cfg["dtype"],
+                                          shape=(cfg["Nr"], cfg["Nc"]), device_ptr=xi.data_ptr()))
+        del xi
 
-    if cfg["extra"]:
+    if nbatch > 1:
+        def step():
+            for Wi in Ws:
+                Wi.forward()
+                Wi.inverse()
+    elif cfg["extra"]:
         def step():
             W.forward()
             W.soft_threshold(0.5)
@@ -305,10 +336,12 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
         sanity["norm1_ranks"] = len(parts)
         W.inverse()
 
-    pixels = cfg["Nr"] * cfg["Nc"]
+    pixels = cfg["Nr"] * cfg["Nc"] * nbatch
     ms_per_step = elapsed / steps * 1e3
     value = world * pixels / (elapsed / steps) / 1e6
     step_bytes, per_kernel_bytes = algorithmic_bytes(cfg, levels_eff)
+    step_bytes *= nbatch
+    per_kernel_bytes = {k: v * nbatch for k, v in per_kernel_bytes.items()}
 
     roofline = None
     kernels = {}
@@ -333,19 +366,21 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
             # HBM bytes per launch: NOT measured in this run (PMC counters need rocprofv3 passes of their own).  The figure is
             # the one committed under profiles/ for this kernel -- (2*FETCH_SIZE + WRITE_SIZE) per the gfx950 correction of
             # MI355X_MICROARCH.md -- marked static with the commit it was taken at; null when the kernel has none.
-            traffic, tsrc, tcommit = None, None, None
+            traffic, tsrc, tcommit, tstale = None, None, None, None
             tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tfile):
                 try:
                     tj = json.load(open(tfile))
-                    ent = tj.get(name, {}).get(dom)
+                    ent = tj.get("c2" if name == "c2_batch" else name, {}).get(dom)
                     if ent:
                         traffic, tsrc, tcommit = ent["hbm_bytes_per_launch"], tj.get("source"), ent.get("commit", tj.get("commit"))
+                        # stale = the kernel sources changed since the counters were collected (hash kept with the entry)
+                        tstale = ent.get("src_sha16") != kernel_source_hash()
                 except Exception:
                     pass
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_static": traffic is not None,
-                        "traffic_commit": tcommit, "traffic_source": tsrc,
+                        "traffic_commit": tcommit, "traffic_stale": tstale, "traffic_source": tsrc,
                         "algorithmic_bytes_per_launch": kb / kernels[dom]["launches_per_step"],
                         "avg_launch_us": round(kernels[dom]["avg_us"], 2), "launches_per_step": kernels[dom]["launches_per_step"],
                         "step_compulsory_bytes": step_bytes,
@@ -358,22 +393,27 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
         # the working set fits the 256 MB Infinity Cache (tools/copy_ceiling.py: 6.6-7.2 TB/s up to 256 MB moved, 4.7-4.9 TB/s beyond 1 GB).
         try:
             nbytes = int(roofline["algorithmic_bytes_per_launch"]) // 2
-            a_ = torch.empty(nbytes // 4, device="cuda", dtype=torch.float32).normal_()
-            b_ = torch.empty_like(a_)
-            for _ in range(3):
+            # (a batch config rotates through as many distinct buffer pairs as it has images, so that the copy streams through HBM too)
+            pairs = []
+            for _ in range(nbatch):
+                a_ = torch.empty(nbytes // 4, device="cuda", dtype=torch.float32).normal_()
+                pairs.append((a_, torch.empty_like(a_)))
+            for a_, b_ in pairs[:3]:
                 b_.copy_(a_)
             torch.cuda.synchronize()
             ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            creps = 30
+            creps = max(30 // nbatch, 2)
             ce0.record()
             for _ in range(creps):
-                b_.copy_(a_)
+                for a_, b_ in pairs:
+                    b_.copy_(a_)
             ce1.record()
             torch.cuda.synchronize()
-            cgbps = 2.0 * nbytes / (ce0.elapsed_time(ce1) * 1e-3 / creps) / 1e9
-            roofline["copy_ceiling"] = {"GBps": round(cgbps, 1), "bytes_moved": 2 * nbytes, "achieved_over_copy": round(roofline["achieved"] / cgbps, 4),
-                                        "what": "torch device-to-device copy of the dominant kernel's algorithmic byte volume, 30 repetitions, measured in this run"}
-            del a_, b_
+            cgbps = 2.0 * nbytes * nbatch / (ce0.elapsed_time(ce1) * 1e-3 / creps) / 1e9
+            roofline["copy_ceiling"] = {"GBps": round(cgbps, 1), "bytes_moved": 2 * nbytes, "buffer_pairs_cycled": nbatch,
+                                        "achieved_over_copy": round(roofline["achieved"] / cgbps, 4),
+                                        "what": "torch device-to-device copy of the dominant kernel's algorithmic byte volume (per image), measured in this run"}
+            del pairs
         except Exception as e:
             roofline["copy_ceiling"] = {"error": repr(e)}
 
@@ -402,13 +442,32 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
         roofline["hbm_transform_kernels"] = {"compulsory_bytes": 4 * pixels * 8, "GBps": round(4 * pixels * 8 / t_xf / 1e9, 1) if t_xf > 0 else None,
                                              "frac": round(4 * pixels * 8 / t_xf / 1e9 / HBM_PEAK_GBPS, 4) if t_xf > 0 else None}
 
+    extra_timing = None
+    if cfg["extra"]:
+        # The timed step runs the Python wrapper's default: soft_threshold() leaves sum|c| behind for the norm1() that follows
+        # (safe there: band pointers only leave the wrapper through accessors that switch it off).  The C++ class's default reduces
+        # the bands on every norm1(): the same step timed that way, next to the headline value.
+        W.set_norm_cache(False)
+        for _ in range(5):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        nrep = max(5, min(steps, 20))
+        for _ in range(nrep):
+            step()
+        sync()
+        extra_timing = {"norm1_always_reduce_ms_per_step": round((time.perf_counter() - t1) / nrep * 1e3, 5),
+                        "note": "same step with Wavelets::set_norm_cache(0): the C++ class default (norm1() reduces the bands every time)"}
+        W.set_norm_cache(True)
     cpu = None
     if rank == 0 and world == 1 and cpu_seconds > 0:
         cpu = cpu_baseline(cfg, cpu_seconds)
     del W
+    del Ws
     return {"value": round(value, 1), "unit": cfg["unit"], "ms_per_step": round(ms_per_step, 5), "gpu_ms_per_step": round(gpu_ms / steps, 5),
             "steps": steps, "warmup": warmup, "levels": levels_eff, "workload": cfg["desc"], "dtype": "f32" if cfg["dtype"] == "float32" else "f64",
             "sanity": sanity, "roundtrip_max_rel_err": rt_err, "roofline": roofline, "cpu_baseline": cpu, "power": power,
+            "images_per_step": nbatch, "ms_per_image_pair": round(ms_per_step / nbatch, 5), "extra_timing": extra_timing,
             "kernels": {k: {a: round(b, 3) for a, b in v.items()} for k, v in kernels.items()}}
 
 
@@ -519,7 +578,7 @@ def pdwt_amd_mod():
 
 
 # short timed runs of the other BASELINE configs appended to the headline line ("other_configs"): (steps, warmup, settle ms, cpu s)
-OTHER_RUNS = {"c3": (60, 10, 60.0, 5.0), "c4": (200, 20, 60.0, 5.0), "c5": (30, 5, 60.0, 6.0)}
+OTHER_RUNS = {"c2_batch": (40, 5, 60.0, 0.0), "c3": (60, 10, 60.0, 5.0), "c4": (200, 20, 60.0, 5.0), "c5": (30, 5, 60.0, 6.0)}
 
 
 def main():
@@ -579,7 +638,10 @@ def main():
             "value": res["value"], "unit": cfg["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": res["dtype"], "data": "synthetic",
-            "config": {"workload": cfg["desc"], "images_per_gpu_per_step": 1, "levels": res["levels"], "parallelism": "batch-split x%d (no data-path collective)" % world},
+            "config": {"workload": cfg["desc"], "images_per_gpu_per_step": res["images_per_step"], "levels": res["levels"],
+                       "parallelism": "batch-split x%d (no data-path collective)" % world,
+                       "working_set": ("one image per GPU, transformed over and over: its ~170 MB stay in the 256 MiB Infinity Cache; the same workload on a "
+                                       "batch that streams through HBM is other_configs.c2_batch") if args.config == "c2" else None},
             "gpu_ms_per_step": res["gpu_ms_per_step"], "settle_ms": args.settle_ms, "roundtrip_max_rel_err": res["roundtrip_max_rel_err"],
             "sanity": res["sanity"], "roofline": res["roofline"], "cpu_baseline": res["cpu_baseline"], "power": res["power"],
             "kernels": res["kernels"], "other_configs": others,

@@ -14,7 +14,7 @@ import sys
 
 cfg, fdir, wdir = sys.argv[1], sys.argv[2], sys.argv[3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KMAP = {"k_fwd2d_casc": "fwd2d_casc", "k_inv2d_casc": "inv2d_casc", "k_inv2d_cascw": "inv2d_casc", "k_fwd2d_stream": "fwd2d_stream", "k_fwd2d_fused": "fwd2d_fused", "k_inv2d_stream": "inv2d_stream", "k_inv2d_fused": "inv2d_fused",
+KMAP = {"k_fwd2d_casc": "fwd2d_casc", "k_inv2d_casc": "inv2d_casc", "k_inv2d_cascw": "inv2d_casc", "k_inv2d_casc3": "inv2d_casc", "k_fwd2d_stream": "fwd2d_stream", "k_fwd2d_fused": "fwd2d_fused", "k_inv2d_stream": "inv2d_stream", "k_inv2d_fused": "inv2d_fused",
         "k_fwd2d_f64fused": "fwd2d_f64", "k_inv2d_f64fused": "inv2d_f64", "k_fwd2d_f64lds": "fwd2d_f64", "k_inv2d_f64lds": "inv2d_f64", "k_soft_thresh_sum": "thresh_sum", "k_soft_thresh": "soft_thresh", "k_abs_sum": "abs_sum",
         "k_ana_rows": "ana_rows", "k_ana_rows_tr": "ana_rows", "k_syn_rows_tr": "syn_rows", "k_ana_cols": "ana_cols", "k_syn_rows": "syn_rows", "k_syn_cols": "syn_cols",
         "k_fwd1d_stream": "ana_rows", "k_inv1d_stream": "syn_rows", "k_fwd1d_fused": "ana_rows", "k_inv1d_fused": "syn_rows", "k_inv1d_fused_pf": "syn_rows",
@@ -49,7 +49,10 @@ except Exception:
 doc["source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 10 --warmup 3`; "
                  "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the kernel's launches; summaries in profiles/*_pmc_*.md")
 COMMIT = os.environ.get("PDWT_COMMIT", "")
-doc[cfg] = {k: {"commit": COMMIT, "hbm_bytes_per_launch": (2 * fetch[k] + write.get(k, 0.0)) * 1024, "fetch_kb_raw": fetch[k], "write_kb": write.get(k, 0.0), "launches_sampled": nf[k]}
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash  # noqa: E402  (bench.py flags an entry whose hash differs from the sources it runs: traffic_stale)
+SRC = kernel_source_hash()
+doc[cfg] = {k: {"commit": COMMIT, "src_sha16": SRC, "hbm_bytes_per_launch": (2 * fetch[k] + write.get(k, 0.0)) * 1024, "fetch_kb_raw": fetch[k], "write_kb": write.get(k, 0.0), "launches_sampled": nf[k]}
             for k in fetch}
 json.dump(doc, open(out_path, "w"), indent=1, sort_keys=True)
 print(json.dumps(doc[cfg], indent=1))
