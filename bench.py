@@ -442,6 +442,39 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
         roofline["hbm_transform_kernels"] = {"compulsory_bytes": 4 * pixels * 8, "GBps": round(4 * pixels * 8 / t_xf / 1e9, 1) if t_xf > 0 else None,
                                              "frac": round(4 * pixels * 8 / t_xf / 1e9 / HBM_PEAK_GBPS, 4) if t_xf > 0 else None}
 
+    clock_probe = None
+    if cfg["dtype"] == "float64" and not cfg["do_swt"] and cfg["ndim"] == 2 and hasattr(L, "pdwt_clock_probe_enable"):
+        # In-kernel clock of the level-1 launches (the probe of dwt_lds.hip: shader-clock counter over the 100 MHz counter, workgroup 0)
+        # next to what amdsmi reports for the SAME window -- VERDICT r2: the two instruments disagreed (1.4-1.5 GHz vs 2.29 GHz)
+        L.pdwt_clock_probe_enable(1)
+        for _ in range(3):
+            step()
+        sync()
+        SLOTS = (("fwd_level1", 1), ("inv_level1", 9), ("fwd_level2", 2), ("inv_level2", 10))
+
+        def read_slots():
+            out = {}
+            for nm, slot in SLOTS:
+                mhz, us = C.c_double(), C.c_double()
+                if L.pdwt_clock_probe_read(slot, C.byref(mhz), C.byref(us)) == 0 and us.value > 0:
+                    out[nm] = (mhz.value, us.value)
+            return out
+        pw0 = time.time()
+        nprobe = max(5, min(steps, 30))
+        acc = {}
+        for _ in range(4):  # four sustained runs of nprobe back-to-back steps: the probe holds the LAST launch of each kind
+            for _ in range(nprobe):
+                step()
+            sync()
+            for nm, v in read_slots().items():
+                acc.setdefault(nm, []).append(v)
+        pw1 = time.time()
+        L.pdwt_clock_probe_enable(0)
+        clock_probe = {k: {"shader_mhz_median": round(sorted(m for m, _ in v)[len(v) // 2], 1), "shader_mhz_min": round(min(m for m, _ in v), 1),
+                           "workgroup0_us_median": round(sorted(u for _, u in v)[len(v) // 2], 1), "samples": len(v)} for k, v in acc.items()}
+        clock_probe["amdsmi_same_window"] = _SAMPLER.window(pw0, pw1) if _SAMPLER is not None else None
+        clock_probe["what"] = ("s_memtime / s_memrealtime of workgroup 0 of the 8192^2 (level 1) and 4096^2 (level 2) launches: the last step of "
+                               "each of four sustained back-to-back runs of %d steps" % nprobe)
     extra_timing = None
     if cfg["extra"]:
         # The timed step runs the Python wrapper's default: soft_threshold() leaves sum|c| behind for the norm1() that follows
@@ -467,7 +500,7 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
     return {"value": round(value, 1), "unit": cfg["unit"], "ms_per_step": round(ms_per_step, 5), "gpu_ms_per_step": round(gpu_ms / steps, 5),
             "steps": steps, "warmup": warmup, "levels": levels_eff, "workload": cfg["desc"], "dtype": "f32" if cfg["dtype"] == "float32" else "f64",
             "sanity": sanity, "roundtrip_max_rel_err": rt_err, "roofline": roofline, "cpu_baseline": cpu, "power": power,
-            "images_per_step": nbatch, "ms_per_image_pair": round(ms_per_step / nbatch, 5), "extra_timing": extra_timing,
+            "images_per_step": nbatch, "ms_per_image_pair": round(ms_per_step / nbatch, 5), "extra_timing": extra_timing, "clock_probe": clock_probe,
             "kernels": {k: {a: round(b, 3) for a, b in v.items()} for k, v in kernels.items()}}
 
 
@@ -644,6 +677,7 @@ def main():
                                        "batch that streams through HBM is other_configs.c2_batch") if args.config == "c2" else None},
             "gpu_ms_per_step": res["gpu_ms_per_step"], "settle_ms": args.settle_ms, "roundtrip_max_rel_err": res["roundtrip_max_rel_err"],
             "sanity": res["sanity"], "roofline": res["roofline"], "cpu_baseline": res["cpu_baseline"], "power": res["power"],
+            "extra_timing": res.get("extra_timing"), "clock_probe": res.get("clock_probe"),
             "kernels": res["kernels"], "other_configs": others,
         }
         print(json.dumps(line), flush=True)

@@ -105,6 +105,12 @@ int pdwt_graph_capture_begin(void);
 int pdwt_graph_capture_end(void** exec_out);
 int pdwt_graph_launch(void* exec);
 int pdwt_graph_destroy(void* exec);
+/* In-kernel clock probe of the fused level kernels of dwt_lds.hip (the C5 kernels): while enabled, workgroup 0 of every such
+ * launch records the shader-clock counter and the 100 MHz real-time counter at its start and end.  slot = direction * 8 + size
+ * class (forward 0, inverse 8; class 0 = 16384 rows, 1 = 8192, 2 = 4096, ...): the last launch of that kind.  shader_mhz = the
+ * clock the workgroup actually ran at, span_us its lifetime; 0 when nothing was recorded.  Synchronises the stream. */
+int pdwt_clock_probe_enable(int on);
+int pdwt_clock_probe_read(int slot, double* shader_mhz, double* span_us);
 int pdwt_ktime_enable(int on);
 int pdwt_ktime_reset(void);
 int pdwt_ktime_read(int kernel_id, int* n_launches, double* total_ms);

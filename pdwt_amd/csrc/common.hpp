@@ -90,6 +90,20 @@ inline int lds_opt_in()
     return PDWT_OK;
 }
 
+// ---- in-kernel clock probe (pdwt_clock_probe_*, runtime.hip) ----------------------------------------------------
+// Workgroup 0 of a probed launch stores (s_memtime, s_memrealtime) when it starts and when it ends: the shader-clock count over
+// the constant 100 MHz count = the clock the kernel actually ran at, to be compared with what amdsmi reports for the same
+// window (bench.py --config c5).  slot = 16 records of 4 x u64; nullptr while the probe is off (the default).
+unsigned long long* clock_probe_slot(int slot);
+inline int clock_probe_size_class(int rows) { int c = 0; while ((rows << c) < 16384 && c < 7) c++; return c; }  // 16384 rows -> 0, 8192 -> 1, ...
+__device__ __forceinline__ void clock_probe_stamp(unsigned long long* probe, int second)
+{
+    if (probe && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        probe[2 * second] = clock64();
+        probe[2 * second + 1] = wall_clock64();
+    }
+}
+
 // ---- tuning / test knobs ------------------------------------------------------------------------
 // Every PDWT_* environment knob is read ONCE (first use of the table), never on the enqueue path; tests and tuning
 // scripts change a value at run time through pdwt_debug_set("<name>", value).  Names and meaning: INTEGRATION.md.

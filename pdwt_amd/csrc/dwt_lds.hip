@@ -130,8 +130,9 @@ struct F64Lds {
 template <typename T, int HLEN>
 __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read through kernarg_taps()*/, const T* __restrict__ in,
                                                           T* __restrict__ cA, T* __restrict__ cH, T* __restrict__ cV,
-                                                          T* __restrict__ cD, int Nr, int Nc, int RO, int strips)
+                                                          T* __restrict__ cD, int Nr, int Nc, int RO, int strips, unsigned long long* probe)
 {
+    clock_probe_stamp(probe, 0);
     using G = F64Lds<T, HLEN>;
     using V2 = pair_t<T>;
     constexpr int ES = sizeof(T);
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read thro
             }
         }
     }
+    clock_probe_stamp(probe, 1);
 }
 
 // =================================================================================================
@@ -406,7 +408,8 @@ static int launch_fwd_f64lds(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, in
     }
     KTimer kt(K_FWD2D_F64);
     constexpr size_t lds = G::kLdsBytes;
-    hipLaunchKernelGGL((k_fwd2d_f64lds<T, HLEN>), dim3(strips * chunks), dim3(kNT), lds, stream(), tt, in, cA, cH, cV, cD, nr, nc, RO, strips);
+    hipLaunchKernelGGL((k_fwd2d_f64lds<T, HLEN>), dim3(strips * chunks), dim3(kNT), lds, stream(), tt, in, cA, cH, cV, cD, nr, nc, RO, strips,
+                       clock_probe_slot(clock_probe_size_class(nr)));
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -495,8 +498,10 @@ struct F64Inv {
 template <typename T, int HLEN, int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable<T> /*read through kernarg_taps()*/, const T* __restrict__ cA,
                                                           const T* __restrict__ cH, const T* __restrict__ cV,
-                                                          const T* __restrict__ cD, T* __restrict__ out, int Nri, int Nci, int Nro, int Nco, int NP, int strips)
+                                                          const T* __restrict__ cD, T* __restrict__ out, int Nri, int Nci, int Nro, int Nco, int NP, int strips,
+                                                          unsigned long long* probe)
 {
+    clock_probe_stamp(probe, 0);
     using G = F64Inv<T, HLEN, NT>;
     using V2 = pair_t<T>;
     constexpr int ES = sizeof(T);
@@ -694,6 +699,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
             }
         }
     }
+    clock_probe_stamp(probe, 1);
 }
 
 // (zero-padded like the forward bank: out[n] = sum_k c[k] IL[n - 2k + hlen/2 - 1], so q = (HLEN-hlen)/2 zeros in FRONT of the bank
@@ -720,7 +726,8 @@ static int launch_inv_f64lds(const T* cA, const T* cH, const T* cV, const T* cD,
     }
     KTimer kt(K_INV2D_F64);
     constexpr size_t lds256 = F64Inv<T, HLEN, 256>::kLdsBytes;
-    hipLaunchKernelGGL((k_inv2d_f64lds<T, HLEN, 256>), dim3(strips * chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, nro, nco, NP, strips);
+    hipLaunchKernelGGL((k_inv2d_f64lds<T, HLEN, 256>), dim3(strips * chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, nro, nco, NP, strips,
+                       clock_probe_slot(8 + clock_probe_size_class(nro)));
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }

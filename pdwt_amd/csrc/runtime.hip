@@ -101,6 +101,21 @@ int knob_get(const char* name, int* value)
     return PDWT_EINVAL;
 }
 
+// ---- in-kernel clock probe ------------------------------------------------------------------------
+static unsigned long long* g_probe[64] = {};
+static bool g_probe_on = false;
+unsigned long long* clock_probe_slot(int slot)
+{
+    if (!g_probe_on || slot < 0 || slot >= 16) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!g_probe[dev]) {
+        if (hipMalloc(&g_probe[dev], 16 * 4 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        (void)hipMemsetAsync(g_probe[dev], 0, 16 * 4 * sizeof(unsigned long long), stream());
+    }
+    return g_probe[dev] + 4 * slot;
+}
+
 // ---- per-kernel timing ---------------------------------------------------------------------
 static const char* const g_knames[K_COUNT] = {
     "fwd2d_fused", "inv2d_fused", "ana_rows", "ana_cols", "syn_cols", "syn_rows",
@@ -319,6 +334,28 @@ int pdwt_graph_destroy(void* exec)
     return PDWT_OK;
 }
 
+int pdwt_clock_probe_enable(int on)
+{
+    g_probe_on = on != 0;
+    return PDWT_OK;
+}
+int pdwt_clock_probe_read(int slot, double* shader_mhz, double* span_us)
+{
+    if (slot < 0 || slot >= 16 || !shader_mhz || !span_us) return PDWT_EINVAL;
+    int dev = 0;
+    PDWT_HIP_TRY(hipGetDevice(&dev));
+    *shader_mhz = *span_us = 0.0;
+    if (dev < 0 || dev >= 64 || !g_probe[dev]) return PDWT_OK;
+    unsigned long long h[4];
+    const int rc = pdwt_memcpy_d2h(h, g_probe[dev] + 4 * slot, sizeof(h));
+    if (rc != PDWT_OK) return rc;
+    if (h[3] > h[1] && h[2] > h[0]) {
+        const double ticks = (double)(h[3] - h[1]);  // 100 MHz
+        *span_us = ticks / 100.0;
+        *shader_mhz = (double)(h[2] - h[0]) / ticks * 100.0;
+    }
+    return PDWT_OK;
+}
 int pdwt_ktime_enable(int on)
 {
     g_kt_on = on != 0;
