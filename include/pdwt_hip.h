@@ -111,6 +111,9 @@ int pdwt_graph_destroy(void* exec);
  * clock the workgroup actually ran at, span_us its lifetime; 0 when nothing was recorded.  Synchronises the stream. */
 int pdwt_clock_probe_enable(int on);
 int pdwt_clock_probe_read(int slot, double* shader_mhz, double* span_us);
+/* diagnostic: enable(2) / enable(3) make EVERY workgroup of the forward / inverse launches record (the last launch wins);
+ * dump copies nblocks x {clk0, t0, clk1, t1} (t in 100 MHz ticks) out.  tools/lds_trace.py */
+int pdwt_clock_probe_dump(unsigned long long* out, int nblocks);
 int pdwt_ktime_enable(int on);
 int pdwt_ktime_reset(void);
 int pdwt_ktime_read(int kernel_id, int* n_launches, double* total_ms);

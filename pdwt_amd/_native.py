@@ -40,7 +40,7 @@ PLAIN_SYMBOLS = ["pdwt_device_count", "pdwt_set_device", "pdwt_get_device", "pdw
                  "pdwt_last_error_string", "pdwt_event_create", "pdwt_event_record", "pdwt_event_sync", "pdwt_event_elapsed_ms",
                  "pdwt_event_destroy", "pdwt_ktime_enable", "pdwt_ktime_reset", "pdwt_ktime_read", "pdwt_kernel_name",
                  "pdwt_kernel_count", "pdwt_graph_allowed", "pdwt_graph_capture_begin", "pdwt_graph_capture_end", "pdwt_graph_launch",
-                 "pdwt_graph_destroy", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set", "pdwt_debug_get", "pdwt_clock_probe_enable", "pdwt_clock_probe_read",
+                 "pdwt_graph_destroy", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set", "pdwt_debug_get", "pdwt_clock_probe_enable", "pdwt_clock_probe_read", "pdwt_clock_probe_dump",
                  "pdwt_sum_scratch_doubles", "pdwt_sum_scratch_read"]
 TYPED_SYMBOLS = (["compute_filters_separable", "create_coeffs_buffer", "free_coeffs_buffer", "copy_coeffs_buffer",
                   "soft_thresh", "soft_thresh_sum", "norm1", "norm1_as_double", "norm1_enqueue", "hard_thresh", "proj_linf", "shrink", "group_soft_thresh",
@@ -89,6 +89,7 @@ def hip():
     L.pdwt_band_size.restype = C.c_longlong
     L.pdwt_band_size.argtypes = [Info, ci, C.POINTER(ci), C.POINTER(ci)]
     L.pdwt_clock_probe_enable.argtypes = [ci]
+    L.pdwt_clock_probe_dump.argtypes = [vp, ci]
     L.pdwt_clock_probe_read.argtypes = [ci, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.pdwt_debug_set.argtypes = [C.c_char_p, ci]
     L.pdwt_debug_get.argtypes = [C.c_char_p, C.POINTER(ci)]

@@ -96,11 +96,18 @@ inline int lds_opt_in()
 // window (bench.py --config c5).  slot = 16 records of 4 x u64; nullptr while the probe is off (the default).
 unsigned long long* clock_probe_slot(int slot);
 inline int clock_probe_size_class(int rows) { int c = 0; while ((rows << c) < 16384 && c < 7) c++; return c; }  // 16384 rows -> 0, 8192 -> 1, ...
-__device__ __forceinline__ void clock_probe_stamp(unsigned long long* probe, int second)
+// all != 0 (pdwt_clock_probe_enable(2), diagnostic): EVERY workgroup records, 4 x u64 each, at probe + 4 * blockIdx.x
+constexpr int kClockProbeAllBlocks = 16384;
+unsigned long long* clock_probe_all(int* all);
+__device__ __forceinline__ void clock_probe_stamp(unsigned long long* probe, int second, int all = 0)
 {
-    if (probe && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        probe[2 * second] = clock64();
-        probe[2 * second + 1] = wall_clock64();
+    if (probe && (all || (blockIdx.x == 0 && blockIdx.y == 0))) {  // (uniform)
+        unsigned long long* const p = probe + (all ? 4 * (size_t)blockIdx.x : (size_t)0);
+        const unsigned long long c = clock64(), t = wall_clock64();
+        if (threadIdx.x == 0) {
+            p[2 * second] = c;
+            p[2 * second + 1] = t;
+        }
     }
 }
 
@@ -140,7 +147,9 @@ enum KnobId {
     KN_F64_LDS,            // LDS-ring form of the fused long double-precision level kernels (dwt_lds.hip)
     KN_F64_LDS_MIN,        // ... smallest level side (pixels)
     KN_F64_LDS_WGS,        // ... workgroups to aim for
-    KN_F64_LDS_MINGROUPS,  // ... shortest chunk, in groups of 4 output rows
+    KN_F64_LDS_MINGROUPS,
+    KN_F64_LDS_SKEW,       // dwt_lds.hip kernels, two workgroups per CU: % of a chunk pair's rows that go to the workgroup dispatched first (0 = even)
+    KN_F64_LDS_PRIO,       // dwt_lds.hip kernels: alternate the issue priority of the two workgroups of a CU step by step (0 = off)  // ... shortest chunk, in groups of 4 output rows
     KN_NORM2SQ_REF1D,      // 1: norm2sq of a 1-D transform adds sum|d| of the detail bands like the reference (src/wt.cu:389) instead of sum d^2
     KN_NORM_IN_THRESHOLD,  // sum|c| computed inside soft_threshold() and returned by the next norm1(): -1 = per instance (set_norm_cache), 0 = never, 1 = always
     KN_COUNT

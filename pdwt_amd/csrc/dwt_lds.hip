@@ -74,6 +74,40 @@ __device__ __forceinline__ void xcd_tile(int strips, int& strip, int& chunk)
     strip = L % strips;
     chunk = L / strips;
 }
+// (strip, first row y0, rows nout) of this workgroup; `chunks` workgroups share a strip.  skew = 0: equal chunks of RO rows.
+// skew > 0: two workgroups share a CU and the issue arbiter serves the OLDER waves first, so the workgroup that was dispatched
+// first runs at full speed, the other at ~0.55 of it, and then finishes alone at half the FP64 issue rate (per-workgroup
+// timestamps, tools/lds_trace.py: 242 vs 347 us forward, 276 vs 400 us inverse at 8192^2 -- and exactly the other way round when the
+// later half is given a higher s_setprio; alternating priorities only moves the first group's end, the launch still ends with
+// the last one).  The rows of a strip are therefore dealt by WEIGHT: skew to a workgroup of the first part of the dispatch order,
+// 100 - skew to one of the second part (boundaries rounded to multiples of 4 rows).
+__device__ __forceinline__ void lds_tile(int strips, int chunks, int RO, int nrows, int skew, int& strip, int& y0, int& nout)
+{
+    if (skew > 0) {
+        // first part of the dispatch order -> the ODD chunks of every strip (never more than half the grid: those workgroups are
+        // the first on their CU), the rest -> the even chunks (each part dealt to the XCDs like xcd_tile does); a strip's rows go
+        // to its chunks by weight, skew : 100 - skew
+        const int T = gridDim.x, E = strips * (chunks >> 1);
+        const int late = (int)blockIdx.x >= E ? 1 : 0;
+        const int wh = blockIdx.x - late * E, n = late ? T - E : E;
+        const int x = wh & 7, per = n >> 3, rem = n & 7;
+        const int P = x * per + min(x, rem) + (wh >> 3);
+        strip = P % strips;
+        const int chunk = 2 * (P / strips) + 1 - late;
+        const int wa = skew, wb = 100 - skew;
+        const int before = wb * ((chunk + 1) >> 1) + wa * (chunk >> 1), total = wb * ((chunks + 1) >> 1) + wa * (chunks >> 1);
+        const int q = (nrows + 3) >> 2;  // groups of 4 rows
+        const int g0 = (int)(((long long)q * before + (total >> 1)) / total);
+        const int g1 = (int)(((long long)q * (before + (late ? wb : wa)) + (total >> 1)) / total);
+        y0 = 4 * g0;
+        nout = min(4 * g1, nrows) - y0;
+    } else {
+        int chunk;
+        xcd_tile(strips, strip, chunk);
+        y0 = chunk * RO;
+        nout = min(RO, nrows - y0);
+    }
+}
 __device__ __forceinline__ void st_sv(double* base, unsigned boff, double v)
 {
     asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(boff), "v"(v), "s"(base) : "memory");
@@ -130,9 +164,10 @@ struct F64Lds {
 template <typename T, int HLEN>
 __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read through kernarg_taps()*/, const T* __restrict__ in,
                                                           T* __restrict__ cA, T* __restrict__ cH, T* __restrict__ cV,
-                                                          T* __restrict__ cD, int Nr, int Nc, int RO, int strips, unsigned long long* probe)
+                                                          T* __restrict__ cD, int Nr, int Nc, int RO, int strips, unsigned long long* probe, int probe_all, int prio_rot, int skew)
 {
-    clock_probe_stamp(probe, 0);
+    clock_probe_stamp(probe, 0, probe_all);
+    const int prio_half = (2 * blockIdx.x >= gridDim.x) ? 1 : 0;
     using G = F64Lds<T, HLEN>;
     using V2 = pair_t<T>;
     constexpr int ES = sizeof(T);
@@ -144,11 +179,9 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read thro
     // the rows are staged: Nv x (Nc + (Nc & 1)) is the virtual image, ceil-half the band size
     const int Nc2 = (Nc + 1) >> 1, Nr2 = (Nr + 1) >> 1;
     const int Nv = Nr + (Nr & 1);
-    int strip, chunk;
-    xcd_tile(strips, strip, chunk);
+    int strip, y0, nout;
+    lds_tile(strips, gridDim.x / strips, RO, Nr2, skew, strip, y0, nout);
     const int i0 = strip * kNCW;
-    const int y0 = chunk * RO;
-    const int nout = min(RO, Nr2 - y0);
     if (nout <= 0) return;
     const int ngroups = (nout + 3) >> 2;
     const int nsteps = ngroups + kLag;
@@ -232,6 +265,18 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read thro
     auto step = [&](auto PHC, int s) {
         constexpr int PH = decltype(PHC)::value;
         constexpr int cbase_row = kNIR * ((PH + kPhases - (kLag % kPhases)) % kPhases) + 2;  // ring row of k = 0 (rp = 0)
+        // Two workgroups share a CU and the issue arbiter prefers the older waves: left alone, the workgroup dispatched first runs at
+        // full speed and the second one crawls, then finishes ALONE at half the FP64 issue rate (one wave per SIMD issues a v_fmac_f64
+        // every 8.5 cycles; per-workgroup timestamps: 223 vs 320 us forward, 267 vs 383 us inverse at 8192^2).  Alternating a user
+        // priority between the two halves of the grid step by step lets both progress together.
+        if (prio_rot == 1) {
+            if ((s + prio_half) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        } else if (prio_rot == 2) {  // (experiments: the later half always first / the earlier half always first)
+            if (prio_half) __builtin_amdgcn_s_setprio(2);
+        } else if (prio_rot == 3) {
+            if (!prio_half) __builtin_amdgcn_s_setprio(2);
+        }
         const int buf = s & 1;
         load_rows();  // rows of step s+1, in flight while this step computes
         const char* xr = in_lds + buf * G::kInBufBytes + row_rd;
@@ -359,7 +404,7 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read thro
             }
         }
     }
-    clock_probe_stamp(probe, 1);
+    clock_probe_stamp(probe, 1, probe_all);
 }
 
 // =================================================================================================
@@ -371,6 +416,22 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read thro
 // db12/sym12/coif4, db16/sym16, db20/sym20.  Measured against the kernels they replace (two levels, 8192^2, forward / inverse):
 // db4 554/664 -> 283/378 us, db8 591/564 -> 312/421, db12 580/647 -> 442/435, db16 1089/1463 -> 477/495.
 #define PDWT_F64LDS_HLENS(X) X(8) X(16) X(24) X(32) X(40)
+
+// uneven split of chunk pairs between the two workgroups of a CU (lds_tile): only when the grid really puts two on every CU
+static int lds_skew(int strips, int chunks)
+{
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cus[dev]) {
+        hipDeviceProp_t p;
+        cus[dev] = hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : -1;
+    }
+    const int T = strips * chunks, sk = knob(KN_F64_LDS_SKEW);
+    if (sk <= 50 || sk >= 100 || cus[dev] <= 0 || chunks < 2 || chunks > 64) return 0;
+    if (T <= cus[dev] || T > 2 * cus[dev]) return 0;
+    return sk;
+}
 
 // HLEN = the instantiated length, hlen <= HLEN the filter's own (even) length: the bank is zero-padded SYMMETRICALLY, q = (HLEN-hlen)/2
 // taps at either end.  out[i] = sum_j x[2i - C + j] F[hlen-1-j] with C = hlen/2 - 1 becomes the same sum over the padded window
@@ -406,10 +467,13 @@ static int launch_fwd_f64lds(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, in
         tt.t[2 * j] = in_bank ? f.a[hlen - 1 - k] : T(0);
         tt.t[2 * j + 1] = in_bank ? f.b[hlen - 1 - k] : T(0);
     }
+    int pall = 0;
+    unsigned long long* const pbuf = clock_probe_all(&pall);  // (diagnostic: every workgroup stamps its start and end)
+    if (strips * chunks > kClockProbeAllBlocks) pall = 0;
     KTimer kt(K_FWD2D_F64);
     constexpr size_t lds = G::kLdsBytes;
     hipLaunchKernelGGL((k_fwd2d_f64lds<T, HLEN>), dim3(strips * chunks), dim3(kNT), lds, stream(), tt, in, cA, cH, cV, cD, nr, nc, RO, strips,
-                       clock_probe_slot(clock_probe_size_class(nr)));
+                       pall == 1 ? pbuf : clock_probe_slot(clock_probe_size_class(nr)), pall == 1 ? 1 : 0, knob(KN_F64_LDS_PRIO), lds_skew(strips, chunks));
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -499,9 +563,10 @@ template <typename T, int HLEN, int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable<T> /*read through kernarg_taps()*/, const T* __restrict__ cA,
                                                           const T* __restrict__ cH, const T* __restrict__ cV,
                                                           const T* __restrict__ cD, T* __restrict__ out, int Nri, int Nci, int Nro, int Nco, int NP, int strips,
-                                                          unsigned long long* probe)
+                                                          unsigned long long* probe, int probe_all, int prio_rot, int skew)
 {
-    clock_probe_stamp(probe, 0);
+    clock_probe_stamp(probe, 0, probe_all);
+    const int prio_half = (2 * blockIdx.x >= gridDim.x) ? 1 : 0;
     using G = F64Inv<T, HLEN, NT>;
     using V2 = pair_t<T>;
     constexpr int ES = sizeof(T);
@@ -511,11 +576,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (Nro, Nco): the output size, 2*Nri or 2*Nri - 1 (odd outputs: the synthesis runs on the even size, the last row / column is not stored)
     const int Nrv = 2 * Nri, Ncv = 2 * Nci;
-    int strip, chunk;
-    xcd_tile(strips, strip, chunk);
+    int strip, p0, np;
+    lds_tile(strips, gridDim.x / strips, NP, Nri, skew, strip, p0, np);
     const int c0 = strip * kINCW;
-    const int p0 = chunk * NP;
-    const int np = min(NP, Nri - p0);
     if (np <= 0) return;
     const int nsteps = (np + 1) >> 1;  // column-synthesis steps; one more step drains the row synthesis
 
@@ -578,6 +641,18 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
 
     auto step = [&](auto UU, int s) {
         constexpr int U = decltype(UU)::value;  // step within the body: window positions 2U, 2U+1 of the body = ring slots 2U+pos+j
+        // Two workgroups share a CU and the issue arbiter prefers the older waves: left alone, the workgroup dispatched first runs at
+        // full speed and the second one crawls, then finishes ALONE at half the FP64 issue rate (one wave per SIMD issues a v_fmac_f64
+        // every 8.5 cycles; per-workgroup timestamps: 223 vs 320 us forward, 267 vs 383 us inverse at 8192^2).  Alternating a user
+        // priority between the two halves of the grid step by step lets both progress together.
+        if (prio_rot == 1) {
+            if ((s + prio_half) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        } else if (prio_rot == 2) {  // (experiments: the later half always first / the earlier half always first)
+            if (prio_half) __builtin_amdgcn_s_setprio(2);
+        } else if (prio_rot == 3) {
+            if (!prio_half) __builtin_amdgcn_s_setprio(2);
+        }
         const char* trow = lds_raw + ((s + 1) & 1) * G::kTBufBytes + t_rd;  // the previous step's rows
         T cs1[2], cg1[2], cs0[2], cg0[2];  // column synthesis [position]: IL/IH branch, parity 1/0
         T x1l[2], x1h[2], x0l[2], x0h[2];  // row synthesis [column of the pair]
@@ -699,7 +774,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
             }
         }
     }
-    clock_probe_stamp(probe, 1);
+    clock_probe_stamp(probe, 1, probe_all);
 }
 
 // (zero-padded like the forward bank: out[n] = sum_k c[k] IL[n - 2k + hlen/2 - 1], so q = (HLEN-hlen)/2 zeros in FRONT of the bank
@@ -724,10 +799,13 @@ static int launch_inv_f64lds(const T* cA, const T* cH, const T* cV, const T* cD,
         tt.t[4 * j + 2] = pad(f.b, HLEN - 2 - 2 * j);
         tt.t[4 * j + 3] = pad(f.b, HLEN - 1 - 2 * j);
     }
+    int pall = 0;
+    unsigned long long* const pbuf = clock_probe_all(&pall);
+    if (strips * chunks > kClockProbeAllBlocks) pall = 0;
     KTimer kt(K_INV2D_F64);
     constexpr size_t lds256 = F64Inv<T, HLEN, 256>::kLdsBytes;
     hipLaunchKernelGGL((k_inv2d_f64lds<T, HLEN, 256>), dim3(strips * chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, nro, nco, NP, strips,
-                       clock_probe_slot(8 + clock_probe_size_class(nro)));
+                       pall == 2 ? pbuf : clock_probe_slot(8 + clock_probe_size_class(nro)), pall == 2 ? 1 : 0, knob(KN_F64_LDS_PRIO), lds_skew(strips, chunks));
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }

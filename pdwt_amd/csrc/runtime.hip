@@ -58,7 +58,7 @@ static const KnobDef g_knob_defs[KN_COUNT] = {
     {"rows_tr", "PDWT_ROWS_TR", 1}, {"ring_r", "PDWT_RING_R", 0}, {"ring_waves", "PDWT_RING_WAVES", 4096},
     {"swtf", "PDWT_SWTF", 1}, {"swtf_m", "PDWT_SWTF_M", 0}, {"swtf_mi", "PDWT_SWTF_MI", 0},
     {"swtf_xcd", "PDWT_SWTF_XCD", 1}, {"swtf_perm", "PDWT_SWTF_PERM", 1}, {"swtf_f64", "PDWT_SWTF_F64", 1},
-    {"f64_lds", "PDWT_F64_LDS", 1}, {"f64_lds_min", "PDWT_F64_LDS_MIN", 256}, {"f64_lds_wgs", "PDWT_F64_LDS_WGS", 512}, {"f64_lds_mingroups", "PDWT_F64_LDS_MINGROUPS", 1}, {"norm2sq_ref1d", "PDWT_NORM2SQ_REF1D", 0},
+    {"f64_lds", "PDWT_F64_LDS", 1}, {"f64_lds_min", "PDWT_F64_LDS_MIN", 256}, {"f64_lds_wgs", "PDWT_F64_LDS_WGS", 512}, {"f64_lds_mingroups", "PDWT_F64_LDS_MINGROUPS", 1}, {"f64_lds_skew", "PDWT_F64_LDS_SKEW", 64}, {"f64_lds_prio", "PDWT_F64_LDS_PRIO", 0}, {"norm2sq_ref1d", "PDWT_NORM2SQ_REF1D", 0},
     {"norm_in_threshold", "PDWT_NORM_IN_THRESHOLD", -1},
 };
 static int g_knob_vals[KN_COUNT];
@@ -103,7 +103,19 @@ int knob_get(const char* name, int* value)
 
 // ---- in-kernel clock probe ------------------------------------------------------------------------
 static unsigned long long* g_probe[64] = {};
+static unsigned long long* g_probe_allbuf[64] = {};
 static bool g_probe_on = false;
+static int g_probe_all = 0;  // 0 = off, 1 = forward launches, 2 = inverse launches record every workgroup
+unsigned long long* clock_probe_all(int* all)
+{
+    *all = 0;
+    if (!g_probe_all) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!g_probe_allbuf[dev] && hipMalloc(&g_probe_allbuf[dev], (size_t)kClockProbeAllBlocks * 4 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+    *all = g_probe_all;
+    return g_probe_allbuf[dev];
+}
 unsigned long long* clock_probe_slot(int slot)
 {
     if (!g_probe_on || slot < 0 || slot >= 16) return nullptr;
@@ -336,8 +348,16 @@ int pdwt_graph_destroy(void* exec)
 
 int pdwt_clock_probe_enable(int on)
 {
-    g_probe_on = on != 0;
+    g_probe_on = on == 1;
+    g_probe_all = on >= 2 ? on - 1 : 0;  // 2: every workgroup of the forward launches, 3: of the inverse launches (diagnostic)
     return PDWT_OK;
+}
+int pdwt_clock_probe_dump(unsigned long long* out, int nblocks)
+{
+    int dev = 0;
+    PDWT_HIP_TRY(hipGetDevice(&dev));
+    if (!out || nblocks < 1 || nblocks > kClockProbeAllBlocks || dev < 0 || dev >= 64 || !g_probe_allbuf[dev]) return PDWT_EINVAL;
+    return pdwt_memcpy_d2h(out, g_probe_allbuf[dev], (size_t)nblocks * 4 * sizeof(unsigned long long));
 }
 int pdwt_clock_probe_read(int slot, double* shader_mhz, double* span_us)
 {
