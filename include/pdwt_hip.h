@@ -105,6 +105,18 @@ int pdwt_graph_capture_begin(void);
 int pdwt_graph_capture_end(void** exec_out);
 int pdwt_graph_launch(void* exec);
 int pdwt_graph_destroy(void* exec);
+/* ---------------------------------------------------------------------------------------------
+ * Batched 2-D DWT (no reference counterpart: the reference has no batching, TODO.txt:15; BASELINE.json's north star asks for
+ * batched images).  nimg equally sized float32 images, each with its own band table and scratch exactly as for
+ * pdwt_forward_separable_f32 (pdwt_create_coeffs_buffer_f32, pdwt_tmp_elems); every level of ALL images runs in ONE launch.
+ * create returns NULL when the geometry is outside the streaming level kernels (then run the images one by one); the object
+ * only keeps device-side pointer tables: images, bands and scratch stay the caller's and must outlive it.
+ * ------------------------------------------------------------------------------------------- */
+void* pdwt_batch2d_create_f32(int nimg, float* const* d_images, float** const* d_coeffs, float* const* d_tmps, pdwt_info info);
+int pdwt_batch2d_forward_f32(void* batch, const pdwt_filters_f32* f);
+int pdwt_batch2d_inverse_f32(void* batch, const pdwt_filters_f32* f);
+void pdwt_batch2d_destroy(void* batch);
+
 /* In-kernel clock probe of the fused level kernels of dwt_lds.hip (the C5 kernels): while enabled, workgroup 0 of every such
  * launch records the shader-clock counter and the 100 MHz real-time counter at its start and end.  slot = direction * 8 + size
  * class (forward 0, inverse 8; class 0 = 16384 rows, 1 = 8192, 2 = 4096, ...): the last launch of that kind.  shader_mhz = the

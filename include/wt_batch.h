@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "wt.h"
+#include "pdwt_hip.h" /* plain C: the batched-2D entry points and the filter lookup (no device toolkit header) */
 
 /* rows [first, first + count) of shard `shard` out of `nshards` (the first n_rows % nshards shards get one more) */
 inline void w_shard_rows(int n_rows, int nshards, int shard, int* first, int* count)
@@ -97,6 +98,92 @@ class WaveletsBatch {
   private:
     WaveletsBatch(const WaveletsBatch&);
     WaveletsBatch& operator=(const WaveletsBatch&);
+};
+
+/*
+ * A batch of B equally sized 2-D images on ONE device, transformed together: every level of all images in one launch
+ * (pdwt_batch2d_*, include/pdwt_hip.h) when the geometry allows -- small images are launch-bound, six launches per pair whatever
+ * the size -- otherwise image after image.  Each image is an ordinary `Wavelets` instance (it owns image, bands and scratch:
+ * img[b]->get_coeff(...), soft_threshold(...) etc. work as usual between forward() and inverse()); results are those of the
+ * per-image transforms bit for bit.  Float build only for the one-launch form (libpdwt); libpdwtd loops over the images.
+ */
+class WaveletsImages {
+  public:
+    std::vector<Wavelets*> img;
+    int Nr, Nc;
+
+    /* imgs: B contiguous Nr x Nc images (host, or device when memisonhost = 0) */
+    WaveletsImages(DTYPE* imgs, int B, int Nr_, int Nc_, const char* wname, int levels, int memisonhost = 1) : Nr(Nr_), Nc(Nc_), batch_(NULL)
+    {
+        for (int b = 0; b < B; b++) {
+            img.push_back(new Wavelets(imgs + (size_t)b * Nr * Nc, Nr, Nc, wname, levels, memisonhost, 1, 0, 0, 2));
+            img.back()->set_norm_cache(0); /* the batched launches write the bands behind the instances' backs */
+        }
+#ifndef DOUBLEPRECISION
+        if (ok()) {
+            std::vector<float*> di, dt;
+            std::vector<float**> dc;
+            for (int b = 0; b < B; b++) {
+                di.push_back(img[b]->d_image);
+                dc.push_back(img[b]->d_coeffs);
+                dt.push_back(img[b]->d_tmp);
+            }
+            const w_info w = img[0]->winfos;
+            pdwt_info info = {w.ndims, w.Nr, w.Nc, w.nlevels, w.do_swt, w.hlen};
+            if (pdwt_compute_filters_separable_f32(wname, 0, &bank_) == w.hlen)
+                batch_ = pdwt_batch2d_create_f32(B, di.data(), dc.data(), dt.data(), info);
+        }
+#endif
+    }
+    ~WaveletsImages()
+    {
+        if (batch_) pdwt_batch2d_destroy(batch_);
+        for (size_t b = 0; b < img.size(); b++) delete img[b];
+    }
+    bool ok() const
+    {
+        for (size_t b = 0; b < img.size(); b++)
+            if (img[b]->state == W_CREATION_ERROR) return false;
+        return !img.empty();
+    }
+    bool batched() const { return batch_ != NULL; } /* one launch per level over all images */
+    void forward()
+    {
+#ifndef DOUBLEPRECISION
+        if (batch_ && pdwt_batch2d_forward_f32(batch_, &bank_) == 0) {
+            for (size_t b = 0; b < img.size(); b++) img[b]->state = W_FORWARD;
+            return;
+        }
+#endif
+        for (size_t b = 0; b < img.size(); b++) img[b]->forward();
+    }
+    void inverse()
+    {
+#ifndef DOUBLEPRECISION
+        bool all_fwd = true;
+        for (size_t b = 0; b < img.size(); b++) all_fwd = all_fwd && img[b]->state != W_INVERSE && img[b]->state != W_CREATION_ERROR;
+        if (batch_ && all_fwd && pdwt_batch2d_inverse_f32(batch_, &bank_) == 0) {
+            for (size_t b = 0; b < img.size(); b++) img[b]->state = W_INVERSE;
+            return;
+        }
+#endif
+        for (size_t b = 0; b < img.size(); b++) img[b]->inverse();
+    }
+    /* all images, stacked; returns the element count */
+    size_t get_image(DTYPE* out)
+    {
+        size_t n = 0;
+        for (size_t b = 0; b < img.size(); b++) n += (size_t)img[b]->get_image(out + b * (size_t)Nr * Nc);
+        return n;
+    }
+
+  private:
+    void* batch_;
+#ifndef DOUBLEPRECISION
+    pdwt_filters_f32 bank_;
+#endif
+    WaveletsImages(const WaveletsImages&);
+    WaveletsImages& operator=(const WaveletsImages&);
 };
 
 #endif

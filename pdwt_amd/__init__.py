@@ -7,6 +7,6 @@ libraries for tests, bench.py and Python callers -- the shape of the reference's
 binding (README.md:24).
 """
 from ._native import Info, hip, host, require_gpu  # noqa: F401
-from .wavelets import DeviceArray, Wavelets, W_CREATION_ERROR, W_FORWARD, W_INIT, W_INVERSE  # noqa: F401
+from .wavelets import DeviceArray, ImageBatch, Wavelets, W_CREATION_ERROR, W_FORWARD, W_INIT, W_INVERSE  # noqa: F401
 
-__all__ = ["Wavelets", "DeviceArray", "Info", "hip", "host", "require_gpu"]
+__all__ = ["Wavelets", "ImageBatch", "DeviceArray", "Info", "hip", "host", "require_gpu"]

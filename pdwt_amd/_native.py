@@ -41,6 +41,7 @@ PLAIN_SYMBOLS = ["pdwt_device_count", "pdwt_set_device", "pdwt_get_device", "pdw
                  "pdwt_event_destroy", "pdwt_ktime_enable", "pdwt_ktime_reset", "pdwt_ktime_read", "pdwt_kernel_name",
                  "pdwt_kernel_count", "pdwt_graph_allowed", "pdwt_graph_capture_begin", "pdwt_graph_capture_end", "pdwt_graph_launch",
                  "pdwt_graph_destroy", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set", "pdwt_debug_get", "pdwt_clock_probe_enable", "pdwt_clock_probe_read", "pdwt_clock_probe_dump",
+                 "pdwt_batch2d_create_f32", "pdwt_batch2d_forward_f32", "pdwt_batch2d_inverse_f32", "pdwt_batch2d_destroy",
                  "pdwt_sum_scratch_doubles", "pdwt_sum_scratch_read"]
 TYPED_SYMBOLS = (["compute_filters_separable", "create_coeffs_buffer", "free_coeffs_buffer", "copy_coeffs_buffer",
                   "soft_thresh", "soft_thresh_sum", "norm1", "norm1_as_double", "norm1_enqueue", "hard_thresh", "proj_linf", "shrink", "group_soft_thresh",
@@ -89,6 +90,11 @@ def hip():
     L.pdwt_band_size.restype = C.c_longlong
     L.pdwt_band_size.argtypes = [Info, ci, C.POINTER(ci), C.POINTER(ci)]
     L.pdwt_clock_probe_enable.argtypes = [ci]
+    L.pdwt_batch2d_create_f32.restype = vp
+    L.pdwt_batch2d_create_f32.argtypes = [ci, vp, vp, vp, Info]
+    L.pdwt_batch2d_forward_f32.argtypes = [vp, vp]
+    L.pdwt_batch2d_inverse_f32.argtypes = [vp, vp]
+    L.pdwt_batch2d_destroy.argtypes = [vp]
     L.pdwt_clock_probe_dump.argtypes = [vp, ci]
     L.pdwt_clock_probe_read.argtypes = [ci, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.pdwt_debug_set.argtypes = [C.c_char_p, ci]
@@ -171,6 +177,12 @@ def host(dtype):
         for n in ("image_int_ptr", "coeffs_table_ptr", "tmp_int_ptr"):
             getattr(L, "pdwt_wavelets_" + n).restype = C.c_ssize_t
             getattr(L, "pdwt_wavelets_" + n).argtypes = [vp]
+        L.pdwt_images_new.restype = vp
+        L.pdwt_images_new.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci]
+        L.pdwt_images_at.restype = vp
+        L.pdwt_images_at.argtypes = [vp, ci]
+        for n in ("delete", "ok", "batched", "forward", "inverse"):
+            getattr(L, "pdwt_images_" + n).argtypes = [vp]
         L.pdwt_wavelets_coeff_int_ptr.restype = C.c_ssize_t
         L.pdwt_wavelets_coeff_int_ptr.argtypes = [vp, ci]
         _host[dt] = L

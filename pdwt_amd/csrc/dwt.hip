@@ -26,6 +26,9 @@
 #include "cols_ring.hpp"
 #include "rows_tr.hpp"
 #include "dwt1d_fused.hpp"
+#include <new>
+#include <vector>
+
 #include "dwt_lds.hpp"
 #include "dwt_stream.hpp"
 #include "dwt_casc.hpp"
@@ -837,11 +840,143 @@ static int inverse_separable_1d(T* d_image, T** c, T* d_tmp, pdwt_info w, const 
     return PDWT_OK;
 }
 
+
+// =================================================================================================
+// batched 2-D: ONE launch per level over B equally sized float32 images (pdwt_batch2d_*)
+// =================================================================================================
+// Below ~1024^2 a multi-level pair is launch-bound: three dependent launches per direction of a few microseconds each, 24-32 us
+// per pair whatever the size.  A batch of such images (BASELINE.json: "batched 1D/2D images") runs every level of ALL images in
+// one launch of the streaming level kernels (gridDim.y = image, dwt_stream.hip), the per-image pointers in device-side tables
+// built once: 2 L launches per batch and direction instead of 2 L B.  Same kernels, same arithmetic: results are those of the
+// per-image transforms bit for bit.  The reference has no batched entry (its TODO.txt:15 lists multi-GPU / batching as future work).
+static inline bool b2_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+struct Batch2D {
+    int nimg, dev;
+    pdwt_info w;
+    size_t trash_floats;
+    int lev_nr[33], lev_nc[33];
+    StreamBatchF* d_fwd;  // [level][image]
+    StreamBatchI* d_inv;  // [level][image]
+};
+
+static Batch2D* batch2d_create(int nimg, float* const* d_images, float** const* d_coeffs, float* const* d_tmps, pdwt_info w, int hlen)
+{
+    if (nimg < 1 || nimg > 65535 || !d_images || !d_coeffs || !d_tmps || w.ndims != 2 || w.do_swt || w.nlevels < 1 || w.nlevels > 32) return nullptr;
+    if (force_twopass()) return nullptr;
+    // every level must be inside the streaming path, in both directions
+    int nr = w.Nr, nc = w.Nc;
+    for (int lev = 0; lev < w.nlevels; lev++) {
+        if (!fwd2d_stream_takes(nr, nc, hlen) || !inv2d_stream_takes(nr / 2, nc / 2, hlen)) return nullptr;
+        nr /= 2;
+        nc /= 2;
+    }
+    Scratch<float> probe(d_tmps[0], w.Nr, w.Nc, 2);
+    if (probe.trash_floats < 1024) return nullptr;
+    Batch2D* B = new (std::nothrow) Batch2D();
+    if (!B) return nullptr;
+    B->nimg = nimg;
+    B->w = w;
+    B->trash_floats = probe.trash_floats;
+    B->d_fwd = nullptr;
+    B->d_inv = nullptr;
+    if (hipGetDevice(&B->dev) != hipSuccess) {
+        delete B;
+        return nullptr;
+    }
+    const int L = w.nlevels;
+    std::vector<StreamBatchF> hf((size_t)L * nimg);
+    std::vector<StreamBatchI> hi((size_t)L * nimg);
+    for (int b = 0; b < nimg; b++) {
+        float* const* c = d_coeffs[b];
+        Scratch<float> s(d_tmps[b], w.Nr, w.Nc, 2);
+        if (!d_images[b] || !c || !d_tmps[b] || !b2_al16(d_images[b])) {
+            delete B;
+            return nullptr;
+        }
+        // forward: the approximation ping-pongs between the two scratch buffers and lands in band 0 (forward_separable's level loop)
+        const float* in = d_images[b];
+        int pp = 0;
+        for (int lev = 0; lev < L; lev++) {
+            float* aout = (lev == L - 1) ? c[0] : s.ping[pp];
+            hf[(size_t)lev * nimg + b] = StreamBatchF{in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3], (float*)s.t1};
+            if (!b2_al16(aout) || !b2_al16(c[3 * lev + 1]) || !b2_al16(c[3 * lev + 2]) || !b2_al16(c[3 * lev + 3])) {
+                delete B;
+                return nullptr;
+            }
+            in = aout;
+            pp ^= 1;
+        }
+        // inverse: coarse to fine (inverse_separable's level loop)
+        const float* a = c[0];
+        pp = 0;
+        for (int i = L - 1; i >= 0; i--) {
+            float* out = (i == 0) ? d_images[b] : s.ping[pp];
+            hi[(size_t)i * nimg + b] = StreamBatchI{a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], out};
+            a = out;
+            pp ^= 1;
+        }
+    }
+    nr = w.Nr;
+    nc = w.Nc;
+    for (int lev = 0; lev <= L; lev++) {
+        B->lev_nr[lev] = nr;
+        B->lev_nc[lev] = nc;
+        nr /= 2;
+        nc /= 2;
+    }
+    const size_t bf = hf.size() * sizeof(StreamBatchF), bi = hi.size() * sizeof(StreamBatchI);
+    B->d_fwd = (StreamBatchF*)pdwt_malloc(bf);
+    B->d_inv = (StreamBatchI*)pdwt_malloc(bi);
+    if (!B->d_fwd || !B->d_inv || pdwt_memcpy_h2d(B->d_fwd, hf.data(), bf) != PDWT_OK || pdwt_memcpy_h2d(B->d_inv, hi.data(), bi) != PDWT_OK) {
+        pdwt_free(B->d_fwd);
+        pdwt_free(B->d_inv);
+        delete B;
+        return nullptr;
+    }
+    return B;
+}
+
+static int batch2d_forward(Batch2D* B, const pdwt_filters_f32* filt)
+{
+    if (!B || !filt || filt->hlen != B->w.hlen) return PDWT_EINVAL;
+    const Taps2<float> f = taps_fwd<float>(filt);
+    for (int lev = 0; lev < B->w.nlevels; lev++) {
+        const int rc = fwd2d_stream_batch_f32(B->d_fwd + (size_t)lev * B->nimg, B->nimg, B->trash_floats, B->lev_nr[lev], B->lev_nc[lev], B->w.hlen, f);
+        if (rc != PDWT_OK) return rc < 0 ? rc : PDWT_EINVAL;
+    }
+    return PDWT_OK;
+}
+
+static int batch2d_inverse(Batch2D* B, const pdwt_filters_f32* filt)
+{
+    if (!B || !filt || filt->hlen != B->w.hlen) return PDWT_EINVAL;
+    const Taps2<float> f = taps_inv<float>(filt);
+    for (int i = B->w.nlevels - 1; i >= 0; i--) {
+        const int rc = inv2d_stream_batch_f32(B->d_inv + (size_t)i * B->nimg, B->nimg, B->lev_nr[i + 1], B->lev_nc[i + 1], B->w.hlen, f);
+        if (rc != PDWT_OK) return rc < 0 ? rc : PDWT_EINVAL;
+    }
+    return PDWT_OK;
+}
+
 }  // namespace pdwt
 
 using namespace pdwt;
 
 extern "C" {
+void* pdwt_batch2d_create_f32(int nimg, float* const* d_images, float** const* d_coeffs, float* const* d_tmps, pdwt_info info)
+{
+    return batch2d_create(nimg, d_images, d_coeffs, d_tmps, info, info.hlen);
+}
+int pdwt_batch2d_forward_f32(void* batch, const pdwt_filters_f32* f) { return batch2d_forward((Batch2D*)batch, f); }
+int pdwt_batch2d_inverse_f32(void* batch, const pdwt_filters_f32* f) { return batch2d_inverse((Batch2D*)batch, f); }
+void pdwt_batch2d_destroy(void* batch)
+{
+    Batch2D* B = (Batch2D*)batch;
+    if (!B) return;
+    pdwt_free(B->d_fwd);
+    pdwt_free(B->d_inv);
+    delete B;
+}
 int pdwt_debug_set(const char* key, int value) { return pdwt::knob_set(key, value); }
 int pdwt_debug_get(const char* key, int* value) { return pdwt::knob_get(key, value); }
 size_t pdwt_tmp_elems(pdwt_info w) { return 2 * (size_t)(w.Nr > 0 ? w.Nr : 0) * (size_t)(w.Nc > 0 ? w.Nc : 0) + 1024; }

@@ -23,6 +23,8 @@
 // and to the CPU oracle, so the outputs are bit-identical to both (tests/test_gpu_parity.py).
 // Reference code replaced: w_kern_forward_pass1/2, w_kern_inverse_pass1/2 (src/separable.cu:91-328).
 #include "dwt_stream.hpp"
+
+#include <algorithm>
 #include "stream_dev.hpp"
 
 namespace pdwt {
@@ -42,8 +44,18 @@ struct FwdGeom {
 template <int HLEN, int NIN>
 __global__ __launch_bounds__(256) void k_fwd2d_stream(const float* __restrict__ in, float* __restrict__ cA, float* __restrict__ cH,
                                                        float* __restrict__ cV, float* __restrict__ cD, int Nr, int Nc, int R, int VL,
-                                                       float* __restrict__ trash, int trash_mask, ChunkMap cm, TapsLH f)
+                                                       float* __restrict__ trash, int trash_mask, ChunkMap cm, TapsLH f,
+                                                       const StreamBatchF* __restrict__ batch)
 {
+    if (batch) {  // batched launch: image blockIdx.y (uniform: the table entry arrives by scalar loads)
+        const StreamBatchF e = batch[blockIdx.y];
+        in = e.in;
+        cA = e.cA;
+        cH = e.cH;
+        cV = e.cV;
+        cD = e.cD;
+        trash = e.trash;
+    }
     using G = FwdGeom<HLEN, NIN>;
     using VIN = typename VecOf<NIN>::type;
     constexpr int NB = G::NB, C = G::C, WIN = G::WIN, P = NIN / 2;
@@ -228,8 +240,17 @@ struct InvGeom {
 template <int HLEN>
 __global__ __launch_bounds__(256) void k_inv2d_stream(const float* __restrict__ cA, const float* __restrict__ cH,
                                                        const float* __restrict__ cV, const float* __restrict__ cD, float* __restrict__ out,
-                                                       int Nri, int Nci, int RQ, int VL, ChunkMap cm, Taps2<float> f)
+                                                       int Nri, int Nci, int RQ, int VL, ChunkMap cm, Taps2<float> f,
+                                                       const StreamBatchI* __restrict__ batch)
 {
+    if (batch) {  // batched launch: image blockIdx.y
+        const StreamBatchI e = batch[blockIdx.y];
+        cA = e.cA;
+        cH = e.cH;
+        cV = e.cV;
+        cD = e.cD;
+        out = e.out;
+    }
     using G = InvGeom<HLEN>;
     constexpr int H2 = G::H2, C = G::C, SHIFT = G::SHIFT, NB = G::NB, WIN = G::WIN;
     int cy, bx;
@@ -395,7 +416,7 @@ bool stream_enabled() { return knob(KN_STREAM) == 1; }
 
 // rows of output (forward) / coefficient rows (inverse) per wave: enough waves to fill the chip
 // (256 CUs x 4 SIMDs x a few waves), chunks tall enough to amortise the halo rows
-static int pick_rows(int nrows_total, int strips, int unit)
+static int pick_rows(long long nrows_total, int strips, int unit)
 {
     int R = knob(KN_STREAM_R);
     if (R <= 0) {
@@ -412,18 +433,19 @@ static int pick_rows(int nrows_total, int strips, int unit)
 
 template <int HLEN, int NIN>
 static int launch_fwd_n(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, int trash_mask, int nr, int nc,
-                        const Taps2<float>& f2)
+                        const Taps2<float>& f2, const StreamBatchF* batch = nullptr, int nimg = 1)
 {
     TapsLH f;
     for (int k = 0; k < PDWT_MAX_FILTER_WIDTH; k++) f.t[k] = v2f{f2.a[k], f2.b[k]};
     constexpr int MAXVL = FwdGeom<HLEN, NIN>::MAXVL;
     const int strips = idiv_up(nc, MAXVL * NIN);
     const int VL = idiv_up(nc / NIN, strips);
-    const int R = pick_rows(nr / 2, strips, HLEN / 2);
+    const int R = std::min(pick_rows((long long)(nr / 2) * nimg, strips, HLEN / 2), std::max(2, nr / 2));
     dim3 grid;
     const ChunkMap cm = make_map(idiv_up(strips, 4), idiv_up(nr / 2, R), &grid);
+    grid.y = (unsigned)nimg;
     KTimer kt(K_FWD2D_STREAM, true);
-    PDWT_LAUNCH_KT(kt, (k_fwd2d_stream<HLEN, NIN>), grid, dim3(256), 0, in, cA, cH, cV, cD, nr, nc, R, VL, trash, trash_mask, cm, f);
+    PDWT_LAUNCH_KT(kt, (k_fwd2d_stream<HLEN, NIN>), grid, dim3(256), 0, in, cA, cH, cV, cD, nr, nc, R, VL, trash, trash_mask, cm, f, batch);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -431,28 +453,30 @@ static int launch_fwd_n(const float* in, float* cA, float* cH, float* cV, float*
 // work per wave) once a level is too small to fill the chip with wide ones
 template <int HLEN>
 static int launch_fwd(const float* in, float* cA, float* cH, float* cV, float* cD, float* trash, int trash_mask, int nr, int nc,
-                      const Taps2<float>& f)
+                      const Taps2<float>& f, const StreamBatchF* batch = nullptr, int nimg = 1)
 {
     const long long narrow_below = knob(KN_STREAM_NARROW);
     if constexpr (HLEN > 10) {  // the wide form would need 2*HLEN row + 2*HLEN ring register pairs: narrow lanes only
-        return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, trash, trash_mask, nr, nc, f);
+        return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, trash, trash_mask, nr, nc, f, batch, nimg);
     } else {
-        if ((long long)nr * nc <= narrow_below) return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, trash, trash_mask, nr, nc, f);
-        return launch_fwd_n<HLEN, 4>(in, cA, cH, cV, cD, trash, trash_mask, nr, nc, f);
+        if ((long long)nr * nc * nimg <= narrow_below) return launch_fwd_n<HLEN, 2>(in, cA, cH, cV, cD, trash, trash_mask, nr, nc, f, batch, nimg);
+        return launch_fwd_n<HLEN, 4>(in, cA, cH, cV, cD, trash, trash_mask, nr, nc, f, batch, nimg);
     }
 }
 
 template <int HLEN>
-static int launch_inv(const float* cA, const float* cH, const float* cV, const float* cD, float* out, int nri, int nci, const Taps2<float>& f)
+static int launch_inv(const float* cA, const float* cH, const float* cV, const float* cD, float* out, int nri, int nci, const Taps2<float>& f,
+                      const StreamBatchI* batch = nullptr, int nimg = 1)
 {
     constexpr int MAXVL = InvGeom<HLEN>::MAXVL;
     const int strips = idiv_up(nci, MAXVL * 2);
     const int VL = idiv_up(nci / 2, strips);
-    const int RQ = pick_rows(nri, strips, InvGeom<HLEN>::H2);
+    const int RQ = std::min(pick_rows((long long)nri * nimg, strips, InvGeom<HLEN>::H2), std::max(2, nri));
     dim3 grid;
     const ChunkMap cm = make_map(idiv_up(strips, 4), idiv_up(nri, RQ), &grid);
+    grid.y = (unsigned)nimg;
     KTimer kt(K_INV2D_STREAM, true);
-    PDWT_LAUNCH_KT(kt, k_inv2d_stream<HLEN>, grid, dim3(256), 0, cA, cH, cV, cD, out, nri, nci, RQ, VL, cm, f);
+    PDWT_LAUNCH_KT(kt, k_inv2d_stream<HLEN>, grid, dim3(256), 0, cA, cH, cV, cD, out, nri, nci, RQ, VL, cm, f, batch);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -489,6 +513,56 @@ int inv2d_stream_f32(const float* cA, const float* cH, const float* cV, const fl
     switch (hlen) {
 #define X(H) \
     case H: return launch_inv<H>(cA, cH, cV, cD, out, nri, nci, f);
+        PDWT_STREAM_INV_HLENS(X)
+#undef X
+        default: return 1;
+    }
+}
+
+
+bool fwd2d_stream_takes(int nr, int nc, int hlen)
+{
+    if (!stream_enabled() || (nr & 1) || (nc & 3) || nc < 64 || nr < 2 * hlen) return false;
+    switch (hlen) {
+#define X(H) case H:
+        PDWT_STREAM_FWD_HLENS(X)
+#undef X
+        return true;
+        default: return false;
+    }
+}
+bool inv2d_stream_takes(int nri, int nci, int hlen)
+{
+    if (!stream_enabled() || (nci & 1) || nci < 32 || nri < 2 * hlen) return false;
+    switch (hlen) {
+#define X(H) case H:
+        PDWT_STREAM_INV_HLENS(X)
+#undef X
+        return true;
+        default: return false;
+    }
+}
+
+int fwd2d_stream_batch_f32(const StreamBatchF* d_tab, int nimg, size_t trash_floats, int nr, int nc, int hlen, const Taps2<float>& f)
+{
+    if (!d_tab || nimg < 1 || nimg > 65535 || trash_floats < 1024 || !fwd2d_stream_takes(nr, nc, hlen)) return 1;
+    int slots = 1;
+    while (slots < 256 && (size_t)slots * 2 * 1024 <= trash_floats) slots *= 2;
+    switch (hlen) {
+#define X(H) \
+    case H: return launch_fwd<H>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, slots - 1, nr, nc, f, d_tab, nimg);
+        PDWT_STREAM_FWD_HLENS(X)
+#undef X
+        default: return 1;
+    }
+}
+
+int inv2d_stream_batch_f32(const StreamBatchI* d_tab, int nimg, int nri, int nci, int hlen, const Taps2<float>& f)
+{
+    if (!d_tab || nimg < 1 || nimg > 65535 || !inv2d_stream_takes(nri, nci, hlen)) return 1;
+    switch (hlen) {
+#define X(H) \
+    case H: return launch_inv<H>(nullptr, nullptr, nullptr, nullptr, nullptr, nri, nci, f, d_tab, nimg);
         PDWT_STREAM_INV_HLENS(X)
 #undef X
         default: return 1;

@@ -5,6 +5,7 @@
 #include <new>
 
 #include "../../include/wt.h"
+#include "../../include/wt_batch.h"
 
 #define W(h) (static_cast<Wavelets*>(h))
 
@@ -60,4 +61,16 @@ intptr_t pdwt_wavelets_coeffs_table_ptr(void* h)
     return (intptr_t)W(h)->d_coeffs;
 }
 intptr_t pdwt_wavelets_tmp_int_ptr(void* h) { return (intptr_t)W(h)->d_tmp; }
+
+/* batch of equally sized 2-D images, every level of all images in one launch (include/wt_batch.h: WaveletsImages) */
+void* pdwt_images_new(DTYPE* imgs, int B, int Nr, int Nc, const char* wname, int levels, int memisonhost)
+{
+    return new (std::nothrow) WaveletsImages(imgs, B, Nr, Nc, wname, levels, memisonhost);
+}
+void pdwt_images_delete(void* h) { delete static_cast<WaveletsImages*>(h); }
+int pdwt_images_ok(void* h) { return static_cast<WaveletsImages*>(h)->ok() ? 1 : 0; }
+int pdwt_images_batched(void* h) { return static_cast<WaveletsImages*>(h)->batched() ? 1 : 0; }
+void pdwt_images_forward(void* h) { static_cast<WaveletsImages*>(h)->forward(); }
+void pdwt_images_inverse(void* h) { static_cast<WaveletsImages*>(h)->inverse(); }
+void* pdwt_images_at(void* h, int b) { return static_cast<WaveletsImages*>(h)->img[(size_t)b]; } /* borrowed: owned by the batch */
 }

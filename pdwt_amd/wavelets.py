@@ -124,9 +124,9 @@ class Wavelets:
         return Wavelets._from_handle(self, self._L.pdwt_wavelets_copy(self._h))
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not getattr(self, "_borrowed", False):  # (a view into an ImageBatch belongs to the batch)
             self._L.pdwt_wavelets_delete(self._h)
-            self._h = None
+        self._h = None
 
     __del__ = close
 
@@ -299,3 +299,64 @@ class Wavelets:
 
     def coeff_int_ptr(self, num):
         return self._L.pdwt_wavelets_coeff_int_ptr(self._h, int(num))
+
+
+class ImageBatch:
+    """A batch of equally sized 2-D images on one GPU transformed together (include/wt_batch.h: WaveletsImages): every level of ALL
+    images runs in one launch when the geometry is inside the streaming level kernels (``batched``), otherwise image after image.
+    ``imgs``: array (B, Nr, Nc), numpy (host) or a contiguous device tensor.  ``batch[b]`` is the ordinary ``Wavelets`` view of image
+    b (coefficients, thresholds ... between forward() and inverse()); results equal the per-image transforms bit for bit."""
+
+    def __init__(self, imgs, wname, levels, dtype=None):
+        N.require_gpu()
+        dev = _device_source(imgs)
+        if dev is not None:
+            ptr, shape, dt = dev
+            _sync_producer()
+            src, on_host = C.c_void_p(ptr), 0
+        else:
+            imgs = np.asarray(imgs)
+            dt = np.dtype(dtype or (imgs.dtype if imgs.dtype in (np.float32, np.float64) else np.float32))
+            self._keep = np.ascontiguousarray(imgs, dtype=dt)
+            shape, src, on_host = self._keep.shape, self._keep.ctypes.data_as(C.c_void_p), 1
+        assert len(shape) == 3, "imgs must be (B, Nr, Nc)"
+        self.dtype, self.shape, self.wname = np.dtype(dt), tuple(int(v) for v in shape), wname
+        self._L = N.host(self.dtype)
+        self._h = self._L.pdwt_images_new(src, self.shape[0], self.shape[1], self.shape[2], wname.encode(), int(levels), on_host)
+        if not self._h or not self._L.pdwt_images_ok(self._h):
+            raise RuntimeError("ImageBatch creation failed")
+
+    @property
+    def batched(self):
+        return bool(self._L.pdwt_images_batched(self._h))
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, b):
+        if not 0 <= b < self.shape[0]:
+            raise IndexError(b)
+        w = Wavelets.__new__(Wavelets)
+        w.dtype, w.shape, w._L, w.wname = self.dtype, self.shape[1:], self._L, self.wname
+        w._ct = C.c_float if self.dtype == np.float32 else C.c_double
+        w._h, w._borrowed, w._owner = self._L.pdwt_images_at(self._h, int(b)), True, self
+        return w
+
+    def forward(self):
+        self._L.pdwt_images_forward(self._h)
+
+    def inverse(self):
+        self._L.pdwt_images_inverse(self._h)
+
+    def get_images(self):
+        return np.stack([self[b].get_image() for b in range(self.shape[0])])
+
+    def sync(self):
+        return N.hip().pdwt_sync()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pdwt_images_delete(self._h)
+            self._h = None
+
+    __del__ = close

@@ -1116,3 +1116,44 @@ def test_padded_banks_with_non_finite_samples():
             assert len(bad) > 0
             for (r, c) in extra:
                 assert (np.abs(bad - np.array([r, c])).max(axis=1) <= reach).any(), (wname, k, r, c)
+
+
+@pytest.mark.parametrize("case", [(12, 512, 512, "db4", 3, np.float32), (5, 256, 384, "sym8", 2, np.float32), (3, 1024, 512, "db2", 4, np.float32),
+                                  (4, 250, 250, "db4", 2, np.float32), (3, 256, 256, "db4", 2, np.float64)])
+def test_image_batch_one_launch_per_level(case):
+    """include/wt_batch.h WaveletsImages / pdwt_batch2d_*: a batch of equally sized images, every level of ALL images in one launch
+    of the streaming level kernels (gridDim.y = image).  Bands and reconstructions equal the per-image transforms bit for bit
+    (and the oracle within tolerance); geometries outside the streaming kernels (250 x 250) and the double build fall back to
+    image-after-image and give the same results."""
+    B, nr, nc, wname, lev, dt = case
+    x = np.random.RandomState(21).uniform(0, 255, (B, nr, nc)).astype(dt)
+    IB = pdwt_amd.ImageBatch(x, wname, lev)
+    expect_batched = dt == np.float32 and nr % (4 << (lev - 1)) == 0 and nc % (4 << (lev - 1)) == 0
+    assert IB.batched == expect_batched, (IB.batched, expect_batched)
+    IB.forward()
+    singles = []
+    for b in range(B):
+        W = pdwt_amd.Wavelets(x[b], wname, lev)
+        W.forward()
+        singles.append(W)
+        for k, (g, s) in enumerate(zip(IB[b].coeffs, W.coeffs)):
+            assert np.array_equal(g, s), (b, "band", k)
+    O = orc.OracleWavelets(x[0], wname, lev)
+    O.forward()
+    tol = 1e-5 if dt == np.float32 else 1e-10
+    for g, o in zip(IB[0].coeffs, O.coeffs):
+        assert band_err(g, o) <= tol
+    # the images of a batch are ordinary instances between the two launches: threshold one of them
+    IB[1].soft_threshold(3.0)
+    singles[1].soft_threshold(3.0)
+    assert abs(IB[1].norm1_f64() - singles[1].norm1_f64()) <= 1e-12 * singles[1].norm1_f64()
+    IB.inverse()
+    out = IB.get_images()
+    for b in range(B):
+        singles[b].inverse()
+        assert np.array_equal(out[b], singles[b].get_image()), b
+    assert band_err(out[0], x[0]) <= tol
+    # a second round trip on the same batch object
+    IB.forward()
+    IB.inverse()
+    assert band_err(IB.get_images()[2], out[2]) <= 10 * tol
