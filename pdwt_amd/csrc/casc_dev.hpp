@@ -20,28 +20,7 @@ struct CascMap {
     int cpx;     // W == 1: chunk rows per XCD (all 8 XCDs get the same number); W > 1: workgroups per XCD
     int strips;  // strips per chunk row
     int gy;      // W > 1: workgroup-chunk rows (gy * strips workgroups in all)
-    int stag;    // W > 1: hand-off ordered by LDS flags instead of barriers (free-running waves) when != 0; |stag| - 1 = start
-                 // skew between the four wave groups of a SIMD in units of 512 cycles (> 0: the bottom waves start first)
-    int prio;    // W > 1: rotate the issue priority of the waves that share a SIMD (s_setprio per step)
 };
-
-// ---- LDS flags of the workgroup cascade kernels (free-running waves) --------------------------------------------------
-// A producer wave publishes "my hand-off rows are in LDS" by storing a stage number into its flag word; the consumer (the
-// wave above) polls it right before its first read.  LDS operations of one wave execute in order and the flag is written
-// after an lgkmcnt(0), so data precedes flag; the consumer's acquire load keeps its reads behind the poll.
-__device__ __forceinline__ void casc_flag_publish(int* flag, int stage)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __hip_atomic_store(flag, stage, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void casc_flag_wait(int* flag, int stage)
-{
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < stage) __builtin_amdgcn_s_sleep(1);
-}
-__device__ __forceinline__ void casc_start_skew(int units)
-{
-    for (int i = 0; i < units; i++) __builtin_amdgcn_s_sleep(8);
-}
 struct CascBands {
     float *H1, *V1, *D1, *A2, *H2, *V2, *D2;
 };
@@ -91,9 +70,10 @@ constexpr size_t kCascTraceOff = 1u << 20;
 #define CASC_TRACE_STORE(trash, wave_id, aux)
 #endif
 
-// dwt_casc_inv3.hip: three levels, all streamed (hlen 4 and 8); 1 = not taken
-int inv2d_casc3_f32(const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1, const float* A3,
-                    const float* H3, const float* V3, const float* D3, float* out, float* trash, int nr, int nc, int hlen, const Taps2<float>& f);
+// dwt_casc_inv3.hip: three levels, all streamed (A3 != NULL), or two; hlen 4 and 8; 1 = not taken
+int inv2d_casc3_f32(const float* A2, const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1,
+                    const float* A3, const float* H3, const float* V3, const float* D3, float* out, float* trash, int nr, int nc, int hlen,
+                    const Taps2<float>& f);
 
 int inv2d_cascw_f32(const float* A2, const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1,
                     const float* A3, const float* H3, const float* V3, const float* D3, float* out, float* trash, int nr, int nc, int hlen,

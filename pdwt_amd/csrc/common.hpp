@@ -126,10 +126,6 @@ enum KnobId {
     KN_CASC_WG,            // forward cascade: waves stacked per workgroup with LDS ring hand-off (0 = auto, 1 = independent waves)
     KN_CASC_IWG,           // inverse cascade: the same (0 = auto, 1 = independent waves)
     KN_CASC_L3,            // third level folded into the inverse cascade launch: 1 = streamed (dwt_casc_inv3.hip) where it applies, 2 = prologue form only, 0 = never
-    KN_CASC_STAG,          // forward workgroup cascade: 0 = barriers order the LDS hand-off; != 0 = LDS flags (free-running waves), |v| - 1 = start skew per wave group (512-cycle units; > 0 bottom waves first)
-    KN_CASC_ISTAG,         // inverse workgroup cascade: the same
-    KN_CASC_IPRIO,         // inverse workgroup cascade (dwt_casc_inv3.hip): rotate the issue priority of the waves of a SIMD per step
-    KN_CASC_LDSPAD,        // workgroup cascades: request at least this many KB of LDS per workgroup (occupancy experiments)
     KN_STREAM,             // 0: LDS-tiled fused level kernels instead of the streaming ones
     KN_STREAM_R,           // streaming level kernels: rows per wave (0 = auto)
     KN_STREAM_WAVES,       // streaming level kernels: target waves per launch
@@ -147,9 +143,8 @@ enum KnobId {
     KN_F64_LDS,            // LDS-ring form of the fused long double-precision level kernels (dwt_lds.hip)
     KN_F64_LDS_MIN,        // ... smallest level side (pixels)
     KN_F64_LDS_WGS,        // ... workgroups to aim for
-    KN_F64_LDS_MINGROUPS,
+    KN_F64_LDS_MINGROUPS,  // ... shortest chunk, in groups of 4 output rows
     KN_F64_LDS_SKEW,       // dwt_lds.hip kernels, two workgroups per CU: % of a chunk pair's rows that go to the workgroup dispatched first (0 = even)
-    KN_F64_LDS_PRIO,       // dwt_lds.hip kernels: alternate the issue priority of the two workgroups of a CU step by step (0 = off)  // ... shortest chunk, in groups of 4 output rows
     KN_NORM2SQ_REF1D,      // 1: norm2sq of a 1-D transform adds sum|d| of the detail bands like the reference (src/wt.cu:389) instead of sum d^2
     KN_NORM_IN_THRESHOLD,  // sum|c| computed inside soft_threshold() and returned by the next norm1(): -1 = per instance (set_norm_cache), 0 = never, 1 = always
     KN_COUNT

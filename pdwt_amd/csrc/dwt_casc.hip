@@ -135,18 +135,6 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
     unsigned char* const lds_wr = lds_raw + (size_t)(W > 1 && kw > 0 ? kw - 1 : 0) * REG;
     auto lds_ring = [&](unsigned char* reg, int r) { return reinterpret_cast<v4f*>(reg + ((size_t)r * 64 + lane) * 16); };
     auto lds_ring2 = [&](unsigned char* reg, int r) { return reinterpret_cast<v2f*>(reg + (size_t)(HLEN - 2) * 64 * 16 + ((size_t)r * 64 + lane) * 8); };
-    // free-running form (cm.stag != 0): flag word k is written by wave k (stage 1: ring rows in LDS, stage 2: ring2 rows too)
-    int* const lds_flags = reinterpret_cast<int*>(lds_raw + (size_t)(W > 1 ? W - 1 : 0) * REG);
-    const bool flags = (W > 1) && cm.stag != 0;
-    if constexpr (W > 1) {
-        if (flags) {
-            if (lane == 0) lds_flags[kw] = 0;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the only barrier: every wave has just started
-            const int d = (cm.stag > 0 ? cm.stag : -cm.stag) - 1;
-            casc_start_skew(d * (cm.stag > 0 ? (W - 1 - kw) >> 2 : kw >> 2));
-        }
-    }
-
     auto row_pass1 = [&](const v4f& v, v2f (&lh)[2]) {
         float w[WIN1];
 #pragma unroll
@@ -207,7 +195,6 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
         if (kw > 0) {
 #pragma unroll
             for (int r = 0; r < HLEN - 2; r++) *lds_ring(lds_wr, r) = v4f{ring[r][0].x, ring[r][0].y, ring[r][1].x, ring[r][1].y};
-            if (flags) casc_flag_publish(lds_flags + kw, 1);
         }
     }
 
@@ -232,7 +219,6 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                 row_pass1(v[r1], ring[s1]);
             } else if (comp) {
                 if constexpr (W > 1) {  // ... or from the wave below (its ring warm-up rows)
-                    if (flags) casc_flag_wait(lds_flags + kw + 1, 1);
                     const int i0 = 2 * (n - NL1);
                     const v4f q0 = *lds_ring(lds_rd, i0), q1 = *lds_ring(lds_rd, i0 + 1);
                     ring[s0][0] = v2f{q0.x, q0.y};
@@ -272,18 +258,10 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                 row_pass2(ah[0].x, ah[1].x, ring2[a]);
                 if constexpr (W > 1 && a < HLEN - 2) {
                     // first super-body: the wave above needs the row-pass results of this wave's first HLEN-2 A1 rows
-                    if (sb == 0 && kw > 0) {
-                        *lds_ring2(lds_wr, a) = ring2[a];
-                        if constexpr (a == HLEN - 3) {
-                            if (flags) casc_flag_publish(lds_flags + kw, 2);
-                        }
-                    }
+                    if (sb == 0 && kw > 0) *lds_ring2(lds_wr, a) = ring2[a];
                 }
             } else {
-                if constexpr (W > 1) {
-                    if (flags) casc_flag_wait(lds_flags + kw + 1, 2);
-                    ring2[a] = *lds_ring2(lds_rd, min(n - NA, HLEN - 3));
-                }
+                if constexpr (W > 1) ring2[a] = *lds_ring2(lds_rd, min(n - NA, HLEN - 3));
             }
             if constexpr (a & 1) {
                 // A1 rows n-HLEN+1 .. n complete the window of level-2 row (n-(HLEN-1))/2
@@ -310,7 +288,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
         // are written at A1 rows 0..HLEN-3 and first read at A1 row NA >= HLEN -- one barrier after each half of the FIRST
         // super-body (every wave runs both halves: NA1 >= HLEN for rows2 >= 1).  LDS only: the global loads in flight are not drained.
         if constexpr (W > 1) {
-            if (sb == 0 && !flags) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (sb == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
 #ifdef PDWT_CASC_TRACE
         if (sb == 0) CASC_TRACE(3);  // first half super-body done
@@ -318,7 +296,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
         if (sb * HLEN + HLEN / 2 >= NA1) break;
         static_for<HLEN / 2>([&](auto U) { a1_row(std::integral_constant<int, decltype(U)::value + HLEN / 2>{}, sb); });
         if constexpr (W > 1) {
-            if (sb == 0 && !flags) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (sb == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
 #ifdef PDWT_CASC_TRACE
         if (sb == 0) CASC_TRACE(4);  // first super-body done
@@ -643,7 +621,7 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
     if (W == 0) W = 16;  // C2 forward: 25.1 us independent waves, 24.6 W=8, 23.2 W=16 (252 workgroups each)
     if (W != 1 && W != 4 && W != 8 && W != 16) W = 16;
     constexpr size_t REG = casc_fwd_region_bytes<HLEN>();
-    while (W > 1 && (size_t)(W - 1) * REG + 256 > 150 * 1024) W /= 2;  // the hand-off area must fit the 160 KiB of LDS
+    while (W > 1 && (size_t)(W - 1) * REG > 150 * 1024) W /= 2;  // the hand-off area must fit the 160 KiB of LDS
     if (W == 2) W = 1;
     if (W > 1) {
         const int nr4 = nr / 4;
@@ -655,11 +633,9 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
         while (gy > 1 && (nr4 / gy) / W < HLEN / 2) gy--;  // every wave needs >= HLEN/2 level-2 rows (see the kernel)
         if (gy >= 1 && (nr4 / gy) / W >= HLEN / 2) {
             const int nwg = gy * strips;
-            const CascMap cm = {idiv_up(nwg, 8), strips, gy, knob(KN_CASC_STAG), 0};
+            const CascMap cm = {idiv_up(nwg, 8), strips, gy};
             const dim3 grid((unsigned)(8 * cm.cpx));
-            size_t lds = (size_t)(W - 1) * REG + 64 * sizeof(int);  // hand-off regions + flag words
-            // (tuning: a larger LDS request lowers the workgroups per CU, i.e. turns a resident grid into an oversubscribed one)
-            if (knob(KN_CASC_LDSPAD) > 0) lds = std::max(lds, (size_t)knob(KN_CASC_LDSPAD) * 1024);
+            const size_t lds = (size_t)(W - 1) * REG;  // hand-off regions
             // (HLEN row registers in flight instead of HLEN/2 measured slower in this form too: 24.8 vs 24.6 us at W = 8)
             void (*k)(const float*, CascBands, int, int, int, float*, CascMap, TapsLH);
             k = (W == 4) ? k_fwd2d_casc<HLEN, NVD, 4> : (W == 8) ? k_fwd2d_casc<HLEN, NVD, 8> : k_fwd2d_casc<HLEN, NVD, 16>;
@@ -679,7 +655,7 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
     int cpx = (knob(KN_CASC_WAVES) > 0 ? knob(KN_CASC_WAVES) : 1024) / (8 * strips);
     if (cpx > nr / 4 / 4 / 8) cpx = nr / 4 / 4 / 8;
     if (cpx < 1) cpx = 1;
-    const CascMap cm = {cpx, strips, 0, 0, 0};
+    const CascMap cm = {cpx, strips, 0};
     const dim3 grid((unsigned)(8 * idiv_up(cpx * strips, 4)));
     // row registers in flight (= prefetch distance): HLEN/2 measured best (26.2 us vs 26.8 @HLEN, 28.5 @2*HLEN for 4096^2 db4);
     // a shorter pipeline fills and drains faster, and every wave fills and drains at the same time
@@ -723,7 +699,7 @@ static int launch_inv_casc(const CascInvBands& b, float* out, float* trash, int 
     int cpx = (knob(KN_CASC_IWAVES) > 0 ? knob(KN_CASC_IWAVES) : 2048) / (8 * strips);
     if (cpx > nr / 2 / 8 / 8) cpx = nr / 2 / 8 / 8;  // at least 8 level-l coefficient rows per chunk
     if (cpx < 1) cpx = 1;
-    const CascMap cm = {cpx, strips, 0, 0, 0};
+    const CascMap cm = {cpx, strips, 0};
     const dim3 grid((unsigned)(8 * idiv_up(cpx * strips, 4)));
     KTimer kt(K_INV2D_CASC, true);
     constexpr int H2 = HLEN / 2;

@@ -36,7 +36,8 @@ struct CascInv3B {
 template <int HLEN>
 constexpr int casc_inv3_region_bytes() { return (HLEN / 2 - 1) * 64 * (16 + 32); }
 
-template <int HLEN, int W>
+// L3 = false: the same kernel on TWO levels (the A parts of the level-(l+1) rows are loaded like their H, V, D parts; no third ring)
+template <int HLEN, int W, bool L3>
 __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3B b3, float* __restrict__ out, int Nr, int Nc, int VL,
                                                          float* __restrict__ trash, CascMap cm, Taps2<float> f)
 {
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     static_assert(((H2 - 1 + PHI) & 1) == 0, "loop step 0 starts a level-(l+2) window");
     constexpr int NW3 = H2 + T0 - 1;         // level-(l+2) rows the warm-up windows t = 0 .. T0-1 span
     // VMEM instructions between a load and its use (stream_dev.hpp); E = the step is even (4 level-(l+2) loads are issued first)
-    constexpr int kStep = 3 + 2 * (3 + 2);   // odd step: 3 level-(l+1) loads + per A_l row 3 loads and 2 stores
+    constexpr int NL2 = L3 ? 3 : 4;            // level-(l+1) loads per step
+    constexpr int kStep = NL2 + 2 * (3 + 2);   // (odd) step: the level-(l+1) loads + per A_l row 3 loads and 2 stores
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     CASC_TRACE_DECL;
     CASC_TRACE(0);
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     const unsigned voff3 = (unsigned)c3w * 4u, voff2 = (unsigned)cx2w * 4u, voff1 = (unsigned)cx1w * 4u, voffo = (unsigned)(valid ? cx1 : 0) * 8u;
     const lanemask_t vmask = __ballot(valid);
 
-    // LDS: [hand-off regions][flag words]
+    // LDS: the hand-off regions
     constexpr int REG = casc_inv3_region_bytes<HLEN>();
     unsigned char* const lds_rd = lds_raw + (size_t)kw * REG;                    // written by wave kw+1
     unsigned char* const lds_wr = lds_raw + (size_t)(kw > 0 ? kw - 1 : 0) * REG;  // read by wave kw-1
@@ -107,14 +109,6 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     auto lds_l1 = [&](unsigned char* reg, int r, int h) {
         return reinterpret_cast<v4f*>(reg + (size_t)(H2 - 1) * 64 * 16 + (((size_t)r * 2 + h) * 64 + lane) * 16);
     };
-    int* const lds_flags = reinterpret_cast<int*>(lds_raw + (size_t)(W - 1) * REG);
-    const bool flags = cm.stag != 0;
-    if (flags) {
-        if (lane == 0) lds_flags[kw] = 0;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the only barrier: every wave has just started
-        const int d = (cm.stag > 0 ? cm.stag : -cm.stag) - 1;
-        casc_start_skew(d * (cm.stag > 0 ? (W - 1 - kw) >> 2 : kw >> 2));
-    }
 
     v2f r3av[H2], r3hd[H2];               // level l+2 ring, oldest row in slot 0 (rotated by moves: it advances every second step)
     v2f r2av[H2], r2hd[H2];               // level l+1 ring: (A,V) and (H,D) of the lane's column
@@ -191,29 +185,31 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     v2f q1[2][3];  // level l (two A_l rows per step)
     {
         v2f w3av[NW3], w3hd[NW3];
+        if constexpr (L3) {
 #pragma unroll
-        for (int i = 0; i < NW3; i++) {
-            const size_t o = off3(min(i, last3)) + c3w;
-            w3av[i] = v2f{b3.A3[o], b3.V3[o]};
-            w3hd[i] = v2f{b3.H3[o], b3.D3[o]};
-        }
-        {
+            for (int i = 0; i < NW3; i++) {
+                const size_t o = off3(min(i, last3)) + c3w;
+                w3av[i] = v2f{b3.A3[o], b3.V3[o]};
+                w3hd[i] = v2f{b3.H3[o], b3.D3[o]};
+            }
             const size_t o = off3(min(NW3, last3)) + c3w;
             q3[0] = b3.A3[o];
             q3[1] = b3.H3[o];
             q3[2] = b3.V3[o];
             q3[3] = b3.D3[o];
+        } else {
+            q3[0] = q3[1] = q3[2] = q3[3] = 0.f;
         }
 #pragma unroll
         for (int r = 0; r < H2 - 1; r++) {
             const size_t o = off2(r) + cx2w;
-            r2av[r] = v2f{0.f, b.V2[o]};
+            r2av[r] = v2f{L3 ? 0.f : b.A2[o], b.V2[o]};
             r2hd[r] = v2f{b.H2[o], b.D2[o]};
         }
         r2av[H2 - 1] = r2hd[H2 - 1] = v2f{0.f, 0.f};
         {
             const size_t o = off2(H2 - 1) + cx2w;
-            q2[0] = 0.f;
+            q2[0] = L3 ? 0.f : b.A2[o];
             q2[1] = b.H2[o];
             q2[2] = b.V2[o];
             q2[3] = b.D2[o];
@@ -226,7 +222,7 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
             q1[q][2] = *reinterpret_cast<const v2f*>(b.D1 + o);
         }
         // the A parts of the level-(l+1) warm-up rows s2 = 0 .. H2-2: output (s2 + PHI) & 1 of level-(l+2) window (s2 + PHI) >> 1
-        static_for<H2 - 1>([&](auto S2) {
+        if constexpr (L3) static_for<H2 - 1>([&](auto S2) {
             constexpr int s2 = decltype(S2)::value;
             constexpr int t = (s2 + PHI) >> 1, idx3 = (s2 + PHI) & 1;
             v2f av[H2], hd[H2];
@@ -238,10 +234,12 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
             r2av[s2].x = a2_from(av, hd, std::integral_constant<int, 1 - idx3>{});
         });
         // the ring holds the window of step T0 - 1: loop step 0 rotates it and inserts q3
+        if constexpr (L3) {
 #pragma unroll
-        for (int j = 0; j < H2; j++) {
-            r3av[j] = w3av[T0 - 1 + j];
-            r3hd[j] = w3hd[T0 - 1 + j];
+            for (int j = 0; j < H2; j++) {
+                r3av[j] = w3av[T0 - 1 + j];
+                r3hd[j] = w3hd[T0 - 1 + j];
+            }
         }
     }
     CASC_TRACE(1);  // warm-up syntheses done
@@ -249,7 +247,6 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     if (kw > 0) {
 #pragma unroll
         for (int r = 0; r < H2 - 1; r++) *lds_l2(lds_wr, r) = v4f{r2av[r].x, r2av[r].y, r2hd[r].x, r2hd[r].y};
-        if (flags) casc_flag_publish(lds_flags + kw, 1);
     }
 
     float* const tr = trash + (size_t)(blockIdx.x & 7) * Nc;  // a trash ROW (the dispatcher checks the area holds 8 of them)
@@ -301,21 +298,10 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
 
     auto step = [&](auto Pp, int sb) {
         constexpr int p = decltype(Pp)::value;
-        constexpr bool even = (p & 1) == 0;  // (H2 is even: the parity of the step is the parity of p)
-        constexpr int EX = even ? 4 : 0;     // VMEM instructions an even step issues before everything else
+        constexpr bool even = L3 && (p & 1) == 0;  // (H2 is even: the parity of the step is the parity of p)
+        constexpr int EX = even ? 4 : 0;           // VMEM instructions an even step issues before everything else
         const int s = sb * H2 + p;
         const bool l2act = last || (s < nQ);  // the level-(l+1) part runs (afterwards: level-l rows from the hand-off only)
-        if (cm.prio) {
-            // The issue arbiter prefers the OLDEST wave of a SIMD, so the waves that share a SIMD (kw, kw+4, ...) finish one after the
-            // other (timeline: the youngest ends 4 us after the oldest with the same rows).  Rotating a user priority with the step
-            // number gives every wave the same share.
-            switch ((s + (kw >> 2)) & 3) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
-            }
-        }
         if (l2act) {
             const int s2 = H2 - 1 + s;  // the level-(l+1) stream row that completes the window starting at stream row s
             // ---- level l+2: every second step the ring advances by the row that was loaded two steps ago ----
@@ -338,21 +324,25 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
                 }
             }
             // the A part of stream row s2: first (even step: tap parity 1) or second output of the current level-(l+2) window
-            const float a2 = a2_from(r3av, r3hd, std::integral_constant<int, even ? 1 : 0>{});
+            float a2 = 0.f;
+            if constexpr (L3) a2 = a2_from(r3av, r3hd, std::integral_constant<int, even ? 1 : 0>{});
             // ---- level l+1 ----
             constexpr int sl = (H2 - 1 + p) % H2;
             // (no control flow between a counted wait and the re-issue of its registers: the wait, the copies out of the row
             // registers and the next loads always run; WHICH value enters the ring is a select on finished values)
-            asm_wait3<2 * (3 + 2) + EX>(q2[1], q2[2], q2[3]);
-            v4f e = v4f{a2, asm_copy(q2[2]), asm_copy(q2[1]), asm_copy(q2[3])};
-            if (!(last || s2 < nQ)) {  // ... from the wave below (its ring warm-up rows)
-                if (flags) casc_flag_wait(lds_flags + kw + 1, 1);
-                e = *lds_l2(lds_rd, s2 - nQ);
+            if constexpr (L3) {
+                asm_wait3<2 * (3 + 2) + EX>(q2[1], q2[2], q2[3]);
+            } else {
+                asm_wait4<2 * (3 + 2)>(q2[0], q2[1], q2[2], q2[3]);
+                a2 = asm_copy(q2[0]);
             }
+            v4f e = v4f{a2, asm_copy(q2[2]), asm_copy(q2[1]), asm_copy(q2[3])};
+            if (!(last || s2 < nQ)) e = *lds_l2(lds_rd, s2 - nQ);  // ... from the wave below (its ring warm-up rows)
             r2av[sl] = v2f{e.x, e.y};
             r2hd[sl] = v2f{e.z, e.w};
             {
                 const size_t o = off2(min(s2 + 1, last2));  // the row needed one step ahead (clamped to the last one the wave loads)
+                if constexpr (!L3) asm_load_s(q2[0], b.A2 + o, voff2);
                 asm_load_s(q2[1], b.H2 + o, voff2);
                 asm_load_s(q2[2], b.V2 + o, voff2);
                 asm_load_s(q2[3], b.D2 + o, voff2);
@@ -366,7 +356,7 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
             if (l2act) {
                 const v2f a01 = own_pair(synth_col(r2av, r2hd, std::integral_constant<int, p % H2>{}, std::integral_constant<int, 1 - idx>{}));
                 // ---- level l: stream row r1 enters the ring with its H,V,D row ----
-                asm_wait3<2 + (3 + 2) + 3 + EX>(q1[idx][0], q1[idx][1], q1[idx][2]);
+                asm_wait3<2 + (3 + 2) + NL2 + EX>(q1[idx][0], q1[idx][1], q1[idx][2]);
                 ra[sl] = a01;
                 rh[sl] = asm_copy(q1[idx][0]);
                 rv[sl] = asm_copy(q1[idx][1]);
@@ -382,13 +372,9 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
                     if (sb == 0 && kw > 0) {
                         *lds_l1(lds_wr, q, 0) = v4f{ra[sl].x, ra[sl].y, rh[sl].x, rh[sl].y};
                         *lds_l1(lds_wr, q, 1) = v4f{rv[sl].x, rv[sl].y, rd[sl].x, rd[sl].y};
-                        if constexpr (q == H2 - 2) {
-                            if (flags) casc_flag_publish(lds_flags + kw, 2);
-                        }
                     }
                 }
             } else if (r1 - nP < H2 - 1) {
-                if (flags) casc_flag_wait(lds_flags + kw + 1, 2);
                 const v4f e0 = *lds_l1(lds_rd, r1 - nP, 0), e1 = *lds_l1(lds_rd, r1 - nP, 1);
                 ra[sl] = v2f{e0.x, e0.y};
                 rh[sl] = v2f{e0.z, e0.w};
@@ -407,6 +393,7 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     asm_drain1(q3[1]);
     asm_drain1(q3[2]);
     asm_drain1(q3[3]);
+    asm_drain1(q2[0]);
     asm_drain1(q2[1]);
     asm_drain1(q2[2]);
     asm_drain1(q2[3]);
@@ -423,11 +410,11 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
             constexpr int p = decltype(Pp)::value;
             if (!fin) {
                 step(Pp, sb);
-                // hand-off order without flags: level-(l+1) rows are written in the prologue and first read at step nQ-(H2-1) >= 1,
+                // hand-off order: level-(l+1) rows are written in the prologue and first read at step nQ-(H2-1) >= 1,
                 // level-l rows are written during steps 0 .. XS-1 and first read at step nQ >= XS: one barrier after each of the
                 // first XS steps (every wave runs them: nsteps > XS).  LDS only -- the global loads in flight are not drained.
                 if constexpr (p < XS || p == 0) {
-                    if (sb == 0 && !flags) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    if (sb == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 }
                 fin = (sb * H2 + p + 1 >= nsteps);
             }
@@ -443,6 +430,7 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     asm_drain1(q3[1]);
     asm_drain1(q3[2]);
     asm_drain1(q3[3]);
+    asm_drain1(q2[0]);
     asm_drain1(q2[1]);
     asm_drain1(q2[2]);
     asm_drain1(q2[3]);
@@ -461,7 +449,7 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
 // =================================================================================================
 #define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
 
-template <int HLEN>
+template <int HLEN, bool L3>
 static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* out, float* trash, int nr, int nc, const Taps2<float>& f)
 {
     using G = CascInvGeom<HLEN>;
@@ -472,7 +460,7 @@ static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* o
     int Wk = knob(KN_CASC_IWG);
     if (Wk != 4 && Wk != 8 && Wk != 16) Wk = 16;
     constexpr size_t REG = casc_inv3_region_bytes<HLEN>();
-    auto lds_bytes = [&](int w) { return (size_t)(w - 1) * REG + 64 * sizeof(int); };
+    auto lds_bytes = [&](int w) { return (size_t)(w - 1) * REG; };
     const int wgs = knob(KN_CASC_IWAVES) > 0 ? idiv_up(knob(KN_CASC_IWAVES), Wk) : 256;  // default: one workgroup per CU
     // (W, gy) fits when every wave but the last gets >= H2 rows (the hand-off is first read at step nQ-(H2-1) >= 1) and the last
     // one at least one pair; the kernel's split, replayed on the two chunk sizes that occur
@@ -498,14 +486,13 @@ static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* o
     }
     if (!W) return 1;
     const int nwg = gy * strips;
-    const CascMap cm = {idiv_up(nwg, 8), strips, gy, knob(KN_CASC_ISTAG), knob(KN_CASC_IPRIO)};
+    const CascMap cm = {idiv_up(nwg, 8), strips, gy};
     const dim3 grid((unsigned)(8 * cm.cpx));
-    size_t lds = lds_bytes(W);
-    if (knob(KN_CASC_LDSPAD) > 0) lds = std::max(lds, (size_t)knob(KN_CASC_LDSPAD) * 1024);  // (tuning: see launch_fwd_casc)
+    const size_t lds = lds_bytes(W);
     void (*k)(CascInvBands, CascInv3B, float*, int, int, int, float*, CascMap, Taps2<float>);
-    k = (W == 4) ? k_inv2d_casc3<HLEN, 4> : (W == 8) ? k_inv2d_casc3<HLEN, 8> : k_inv2d_casc3<HLEN, 16>;
+    k = (W == 4) ? k_inv2d_casc3<HLEN, 4, L3> : (W == 8) ? k_inv2d_casc3<HLEN, 8, L3> : k_inv2d_casc3<HLEN, 16, L3>;
     if (lds > 64 * 1024) {  // opt-in once per (kernel, device), not per launch
-        const int rc = (W == 4) ? lds_opt_in<k_inv2d_casc3<HLEN, 4>>() : (W == 8) ? lds_opt_in<k_inv2d_casc3<HLEN, 8>>() : lds_opt_in<k_inv2d_casc3<HLEN, 16>>();
+        const int rc = (W == 4) ? lds_opt_in<k_inv2d_casc3<HLEN, 4, L3>>() : (W == 8) ? lds_opt_in<k_inv2d_casc3<HLEN, 8, L3>>() : lds_opt_in<k_inv2d_casc3<HLEN, 16, L3>>();
         if (rc != PDWT_OK) return rc;
     }
     KTimer kt(K_INV2D_CASC, true);
@@ -514,19 +501,21 @@ static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* o
     return PDWT_OK;
 }
 
-// Three levels, all streamed.  PDWT_OK when launched, 1 when the geometry / filter length is outside this path (the caller falls
-// back to the prologue form of dwt_casc_invw.hip).
-int inv2d_casc3_f32(const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1, const float* A3,
-                    const float* H3, const float* V3, const float* D3, float* out, float* trash, int nr, int nc, int hlen, const Taps2<float>& f)
+// Three levels, all streamed (A3 != NULL), or two (A3 == NULL: A2 is read).  PDWT_OK when launched, 1 when the geometry / filter
+// length is outside this path (the caller falls back to dwt_casc_invw.hip).
+int inv2d_casc3_f32(const float* A2, const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1,
+                    const float* A3, const float* H3, const float* V3, const float* D3, float* out, float* trash, int nr, int nc, int hlen,
+                    const Taps2<float>& f)
 {
-    if (knob(KN_CASC_L3) != 1) return 1;  // (2 = the prologue form)
+    const bool l3 = A3 != nullptr;
     if ((nr & 7) || (nc & 7) || nc < 256 || nr < 32 * hlen) return 1;
     if (!al16(out) || !al16(H1) || !al16(V1) || !al16(D1) || !al16(H2) || !al16(V2) || !al16(D2) || !al16(trash)) return 1;
-    const CascInvBands b = {nullptr, H2, V2, D2, H1, V1, D1};
+    if (!l3 && !al16(A2)) return 1;
+    const CascInvBands b = {A2, H2, V2, D2, H1, V1, D1};
     const CascInv3B b3 = {A3, H3, V3, D3};
     switch (hlen) {
-        case 4: return launch_inv_casc3<4>(b, b3, out, trash, nr, nc, f);
-        case 8: return launch_inv_casc3<8>(b, b3, out, trash, nr, nc, f);
+        case 4: return l3 ? launch_inv_casc3<4, true>(b, b3, out, trash, nr, nc, f) : launch_inv_casc3<4, false>(b, b3, out, trash, nr, nc, f);
+        case 8: return l3 ? launch_inv_casc3<8, true>(b, b3, out, trash, nr, nc, f) : launch_inv_casc3<8, false>(b, b3, out, trash, nr, nc, f);
         default: return 1;
     }
 }

@@ -101,15 +101,6 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
         return reinterpret_cast<v4f*>(reg + (size_t)(H2 - 1) * 64 * 16 + (((size_t)r * 2 + h) * 64 + lane) * 16);
     };
     float* const lds_a2 = reinterpret_cast<float*>(lds_raw + (size_t)(W - 1) * REG + (size_t)kw * kInvA2Rows * 256);
-    // free-running form (cm.stag != 0): flag word k is written by wave k (stage 1: level-(l+1) ring rows in LDS, stage 2: level-l rows too)
-    int* const lds_flags = reinterpret_cast<int*>(lds_raw + (size_t)(W - 1) * REG + (L3 ? (size_t)W * kInvA2Rows * 256 : 0));
-    const bool flags = cm.stag != 0;
-    if (flags) {
-        if (lane == 0) lds_flags[kw] = 0;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the only barrier: every wave has just started
-        const int d = (cm.stag > 0 ? cm.stag : -cm.stag) - 1;
-        casc_start_skew(d * (cm.stag > 0 ? (W - 1 - kw) >> 2 : kw >> 2));
-    }
 
     v2f r2av[H2], r2hd[H2];               // level l+1 ring: (A,V) and (H,D) of the lane's column
     v2f ra[H2], rh[H2], rv[H2], rd[H2];   // level l ring: the lane's two columns of each band
@@ -240,7 +231,6 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
     if (kw > 0) {
 #pragma unroll
         for (int r = 0; r < H2 - 1; r++) *lds_l2(lds_wr, r) = v4f{r2av[r].x, r2av[r].y, r2hd[r].x, r2hd[r].y};
-        if (flags) casc_flag_publish(lds_flags + kw, 1);
     }
 
     float* const tr = trash + (size_t)(blockIdx.x & 7) * Nc;  // a trash ROW (the dispatcher checks the area holds 8 of them)
@@ -331,10 +321,7 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
             // registers and the next loads always run; WHICH value enters the ring is a select on finished values)
             asm_wait4<kWait2>(q2[0], q2[1], q2[2], q2[3]);
             v4f e = v4f{asm_copy(q2[0]), asm_copy(q2[2]), asm_copy(q2[1]), asm_copy(q2[3])};
-            if (!(last || s2 < nQ)) {  // ... from the wave below (its ring warm-up rows)
-                if (flags) casc_flag_wait(lds_flags + kw + 1, 1);
-                e = *lds_l2(lds_rd, s2 - nQ);
-            }
+            if (!(last || s2 < nQ)) e = *lds_l2(lds_rd, s2 - nQ);  // ... from the wave below (its ring warm-up rows)
             r2av[sl] = v2f{e.x, e.y};
             r2hd[sl] = v2f{e.z, e.w};
             {
@@ -371,13 +358,9 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
                     if (sb == 0 && kw > 0) {
                         *lds_l1(lds_wr, q, 0) = v4f{ra[sl].x, ra[sl].y, rh[sl].x, rh[sl].y};
                         *lds_l1(lds_wr, q, 1) = v4f{rv[sl].x, rv[sl].y, rd[sl].x, rd[sl].y};
-                        if constexpr (q == H2 - 2) {
-                            if (flags) casc_flag_publish(lds_flags + kw, 2);
-                        }
                     }
                 }
             } else if (r1 - nP < H2 - 1) {
-                if (flags) casc_flag_wait(lds_flags + kw + 1, 2);
                 const v4f e0 = *lds_l1(lds_rd, r1 - nP, 0), e1 = *lds_l1(lds_rd, r1 - nP, 1);
                 ra[sl] = v2f{e0.x, e0.y};
                 rh[sl] = v2f{e0.z, e0.w};
@@ -413,7 +396,7 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_cascw(CascInvBands b, CascInv3
                 // rows are written during steps 0 .. XS-1 and first read at step nQ >= XS: one barrier after each of the first
                 // XS steps (every wave runs them: nsteps > XS).  LDS only -- the global loads in flight are not drained.
                 if constexpr (p < XS || p == 0) {
-                    if (sb == 0 && !flags) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    if (sb == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 }
                 fin = (sb * H2 + p + 1 >= nsteps);
             }
@@ -455,7 +438,7 @@ static int launch_inv_cascw(const CascInvBands& b, const CascInv3* b3, float* ou
     if (Wk != 4 && Wk != 8 && Wk != 16) Wk = 8;
     constexpr size_t REG = casc_inv_region_bytes<HLEN>();
     const bool l3 = b3 != nullptr;
-    auto lds_bytes = [&](int w) { return (size_t)(w - 1) * REG + (l3 ? (size_t)w * kInvA2Rows * 256 : 0) + 64 * sizeof(int); };
+    auto lds_bytes = [&](int w) { return (size_t)(w - 1) * REG + (l3 ? (size_t)w * kInvA2Rows * 256 : 0); };
     const int wgs = knob(KN_CASC_IWAVES) > 0 ? idiv_up(knob(KN_CASC_IWAVES), Wk) : 256;  // default: one workgroup per CU
     // the kernel's split of R level-(l+1) rows over W waves, replayed: rows of the largest middle wave and of the last wave
     auto split = [&](int R, int w, int* mid, int* lastw) {
@@ -490,10 +473,9 @@ static int launch_inv_cascw(const CascInvBands& b, const CascInv3* b3, float* ou
     }
     if (!W) return 1;
     const int nwg = gy * strips;
-    const CascMap cm = {idiv_up(nwg, 8), strips, gy, knob(KN_CASC_ISTAG), 0};
+    const CascMap cm = {idiv_up(nwg, 8), strips, gy};
     const dim3 grid((unsigned)(8 * cm.cpx));
-    size_t lds = lds_bytes(W);
-    if (knob(KN_CASC_LDSPAD) > 0) lds = std::max(lds, (size_t)knob(KN_CASC_LDSPAD) * 1024);  // (tuning: see launch_fwd_casc)
+    const size_t lds = lds_bytes(W);
     void (*k)(CascInvBands, CascInv3, float*, int, int, int, float*, CascMap, Taps2<float>);
     if (l3) k = (W == 4) ? k_inv2d_cascw<HLEN, 4, true> : (W == 8) ? k_inv2d_cascw<HLEN, 8, true> : k_inv2d_cascw<HLEN, 16, true>;
     else k = (W == 4) ? k_inv2d_cascw<HLEN, 4, false> : (W == 8) ? k_inv2d_cascw<HLEN, 8, false> : k_inv2d_cascw<HLEN, 16, false>;
@@ -520,9 +502,10 @@ int inv2d_cascw_f32(const float* A2, const float* H2, const float* V2, const flo
     if (knob(KN_CASC) != 1 || knob(KN_CASC_IWG) == 1 || !stream_enabled() || !trash) return 1;
     const bool l3 = A3 != nullptr;
     if (l3 && knob(KN_CASC_L3) != 1 && knob(KN_CASC_L3) != 2) return 1;
-    if (l3 && knob(KN_CASC_L3) == 1 && !(knob(KN_CASC_MIN) > (long long)nr * nc)) {
-        // all three levels streamed (dwt_casc_inv3.hip); this file's prologue form takes what that one does not (casc_l3 = 2 forces it)
-        const int rc = inv2d_casc3_f32(H2, V2, D2, H1, V1, D1, A3, H3, V3, D3, out, trash, nr, nc, hlen, f);
+    if (knob(KN_CASC_L3) == 1 && !(knob(KN_CASC_MIN) > (long long)nr * nc)) {
+        // dwt_casc_inv3.hip first: natural-pair arithmetic, all levels streamed (hlen 4 / 8, sizes divisible by 8); this file's
+        // kernels take what that one does not (casc_l3 = 2 forces them)
+        const int rc = inv2d_casc3_f32(A2, H2, V2, D2, H1, V1, D1, A3, H3, V3, D3, out, trash, nr, nc, hlen, f);
         if (rc <= 0) return rc;
     }
     const int m = l3 ? 7 : 3;

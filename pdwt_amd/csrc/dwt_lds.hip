@@ -164,10 +164,9 @@ struct F64Lds {
 template <typename T, int HLEN>
 __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read through kernarg_taps()*/, const T* __restrict__ in,
                                                           T* __restrict__ cA, T* __restrict__ cH, T* __restrict__ cV,
-                                                          T* __restrict__ cD, int Nr, int Nc, int RO, int strips, unsigned long long* probe, int probe_all, int prio_rot, int skew)
+                                                          T* __restrict__ cD, int Nr, int Nc, int RO, int strips, unsigned long long* probe, int probe_all, int skew)
 {
     clock_probe_stamp(probe, 0, probe_all);
-    const int prio_half = (2 * blockIdx.x >= gridDim.x) ? 1 : 0;
     using G = F64Lds<T, HLEN>;
     using V2 = pair_t<T>;
     constexpr int ES = sizeof(T);
@@ -265,18 +264,6 @@ __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read thro
     auto step = [&](auto PHC, int s) {
         constexpr int PH = decltype(PHC)::value;
         constexpr int cbase_row = kNIR * ((PH + kPhases - (kLag % kPhases)) % kPhases) + 2;  // ring row of k = 0 (rp = 0)
-        // Two workgroups share a CU and the issue arbiter prefers the older waves: left alone, the workgroup dispatched first runs at
-        // full speed and the second one crawls, then finishes ALONE at half the FP64 issue rate (one wave per SIMD issues a v_fmac_f64
-        // every 8.5 cycles; per-workgroup timestamps: 223 vs 320 us forward, 267 vs 383 us inverse at 8192^2).  Alternating a user
-        // priority between the two halves of the grid step by step lets both progress together.
-        if (prio_rot == 1) {
-            if ((s + prio_half) & 1) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        } else if (prio_rot == 2) {  // (experiments: the later half always first / the earlier half always first)
-            if (prio_half) __builtin_amdgcn_s_setprio(2);
-        } else if (prio_rot == 3) {
-            if (!prio_half) __builtin_amdgcn_s_setprio(2);
-        }
         const int buf = s & 1;
         load_rows();  // rows of step s+1, in flight while this step computes
         const char* xr = in_lds + buf * G::kInBufBytes + row_rd;
@@ -473,7 +460,7 @@ static int launch_fwd_f64lds(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, in
     KTimer kt(K_FWD2D_F64);
     constexpr size_t lds = G::kLdsBytes;
     hipLaunchKernelGGL((k_fwd2d_f64lds<T, HLEN>), dim3(strips * chunks), dim3(kNT), lds, stream(), tt, in, cA, cH, cV, cD, nr, nc, RO, strips,
-                       pall == 1 ? pbuf : clock_probe_slot(clock_probe_size_class(nr)), pall == 1 ? 1 : 0, knob(KN_F64_LDS_PRIO), lds_skew(strips, chunks));
+                       pall == 1 ? pbuf : clock_probe_slot(clock_probe_size_class(nr)), pall == 1 ? 1 : 0, lds_skew(strips, chunks));
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -563,10 +550,9 @@ template <typename T, int HLEN, int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable<T> /*read through kernarg_taps()*/, const T* __restrict__ cA,
                                                           const T* __restrict__ cH, const T* __restrict__ cV,
                                                           const T* __restrict__ cD, T* __restrict__ out, int Nri, int Nci, int Nro, int Nco, int NP, int strips,
-                                                          unsigned long long* probe, int probe_all, int prio_rot, int skew)
+                                                          unsigned long long* probe, int probe_all, int skew)
 {
     clock_probe_stamp(probe, 0, probe_all);
-    const int prio_half = (2 * blockIdx.x >= gridDim.x) ? 1 : 0;
     using G = F64Inv<T, HLEN, NT>;
     using V2 = pair_t<T>;
     constexpr int ES = sizeof(T);
@@ -641,18 +627,6 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
 
     auto step = [&](auto UU, int s) {
         constexpr int U = decltype(UU)::value;  // step within the body: window positions 2U, 2U+1 of the body = ring slots 2U+pos+j
-        // Two workgroups share a CU and the issue arbiter prefers the older waves: left alone, the workgroup dispatched first runs at
-        // full speed and the second one crawls, then finishes ALONE at half the FP64 issue rate (one wave per SIMD issues a v_fmac_f64
-        // every 8.5 cycles; per-workgroup timestamps: 223 vs 320 us forward, 267 vs 383 us inverse at 8192^2).  Alternating a user
-        // priority between the two halves of the grid step by step lets both progress together.
-        if (prio_rot == 1) {
-            if ((s + prio_half) & 1) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        } else if (prio_rot == 2) {  // (experiments: the later half always first / the earlier half always first)
-            if (prio_half) __builtin_amdgcn_s_setprio(2);
-        } else if (prio_rot == 3) {
-            if (!prio_half) __builtin_amdgcn_s_setprio(2);
-        }
         const char* trow = lds_raw + ((s + 1) & 1) * G::kTBufBytes + t_rd;  // the previous step's rows
         T cs1[2], cg1[2], cs0[2], cg0[2];  // column synthesis [position]: IL/IH branch, parity 1/0
         T x1l[2], x1h[2], x0l[2], x0h[2];  // row synthesis [column of the pair]
@@ -805,7 +779,7 @@ static int launch_inv_f64lds(const T* cA, const T* cH, const T* cV, const T* cD,
     KTimer kt(K_INV2D_F64);
     constexpr size_t lds256 = F64Inv<T, HLEN, 256>::kLdsBytes;
     hipLaunchKernelGGL((k_inv2d_f64lds<T, HLEN, 256>), dim3(strips * chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, nro, nco, NP, strips,
-                       pall == 2 ? pbuf : clock_probe_slot(8 + clock_probe_size_class(nro)), pall == 2 ? 1 : 0, knob(KN_F64_LDS_PRIO), lds_skew(strips, chunks));
+                       pall == 2 ? pbuf : clock_probe_slot(8 + clock_probe_size_class(nro)), pall == 2 ? 1 : 0, lds_skew(strips, chunks));
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }

@@ -51,14 +51,13 @@ static const KnobDef g_knob_defs[KN_COUNT] = {
     {"force_twopass", "PDWT_FORCE_TWOPASS", 0}, {"tiled_cols", "PDWT_TILED_COLS", 0},
     {"casc", "PDWT_CASC", 1}, {"casc_waves", "PDWT_CASC_WAVES", 0}, {"casc_nv", "PDWT_CASC_NV", 0},
     {"casc_min", "PDWT_CASC_MIN", 2048 * 2048}, {"casc_iwaves", "PDWT_CASC_IWAVES", 0}, {"casc_ipfd", "PDWT_CASC_IPFD", 1},
-    {"casc_wg", "PDWT_CASC_WG", 0}, {"casc_iwg", "PDWT_CASC_IWG", 0}, {"casc_l3", "PDWT_CASC_L3", 1},
-    {"casc_stag", "PDWT_CASC_STAG", 0}, {"casc_istag", "PDWT_CASC_ISTAG", 0}, {"casc_iprio", "PDWT_CASC_IPRIO", 0}, {"casc_ldspad", "PDWT_CASC_LDSPAD", 0},
+    {"casc_wg", "PDWT_CASC_WG", 0}, {"casc_iwg", "PDWT_CASC_IWG", 0}, {"casc_l3", "PDWT_CASC_L3", 1}, 
     {"stream", "PDWT_STREAM", 1}, {"stream_r", "PDWT_STREAM_R", 0}, {"stream_waves", "PDWT_STREAM_WAVES", 8192},
     {"stream_narrow", "PDWT_STREAM_NARROW", 2048 * 2048}, {"small", "PDWT_SMALL", 1},
     {"rows_tr", "PDWT_ROWS_TR", 1}, {"ring_r", "PDWT_RING_R", 0}, {"ring_waves", "PDWT_RING_WAVES", 4096},
     {"swtf", "PDWT_SWTF", 1}, {"swtf_m", "PDWT_SWTF_M", 0}, {"swtf_mi", "PDWT_SWTF_MI", 0},
     {"swtf_xcd", "PDWT_SWTF_XCD", 1}, {"swtf_perm", "PDWT_SWTF_PERM", 1}, {"swtf_f64", "PDWT_SWTF_F64", 1},
-    {"f64_lds", "PDWT_F64_LDS", 1}, {"f64_lds_min", "PDWT_F64_LDS_MIN", 256}, {"f64_lds_wgs", "PDWT_F64_LDS_WGS", 512}, {"f64_lds_mingroups", "PDWT_F64_LDS_MINGROUPS", 1}, {"f64_lds_skew", "PDWT_F64_LDS_SKEW", 64}, {"f64_lds_prio", "PDWT_F64_LDS_PRIO", 0}, {"norm2sq_ref1d", "PDWT_NORM2SQ_REF1D", 0},
+    {"f64_lds", "PDWT_F64_LDS", 1}, {"f64_lds_min", "PDWT_F64_LDS_MIN", 256}, {"f64_lds_wgs", "PDWT_F64_LDS_WGS", 512}, {"f64_lds_mingroups", "PDWT_F64_LDS_MINGROUPS", 1}, {"f64_lds_skew", "PDWT_F64_LDS_SKEW", 64}, {"norm2sq_ref1d", "PDWT_NORM2SQ_REF1D", 0},
     {"norm_in_threshold", "PDWT_NORM_IN_THRESHOLD", -1},
 };
 static int g_knob_vals[KN_COUNT];

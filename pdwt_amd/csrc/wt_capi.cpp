@@ -27,6 +27,8 @@ void pdwt_wavelets_inverse(void* h) { W(h)->inverse(); }
 void pdwt_wavelets_soft_threshold(void* h, DTYPE beta, int do_thresh_appcoeffs, int normalize) { W(h)->soft_threshold(beta, do_thresh_appcoeffs, normalize); }
 DTYPE pdwt_wavelets_norm1(void* h) { return W(h)->norm1(); }
 void pdwt_wavelets_set_norm_cache(void* h, int on) { W(h)->set_norm_cache(on); }
+void pdwt_wavelets_norm1_begin(void* h) { W(h)->norm1_begin(); }
+double pdwt_wavelets_norm1_end(void* h) { return W(h)->norm1_end(); }
 /* norm1() before its rounding to DTYPE (per-shard partial sums are combined in double) */
 double pdwt_wavelets_norm1_f64(void* h)
 {

@@ -1157,3 +1157,40 @@ def test_image_batch_one_launch_per_level(case):
     IB.forward()
     IB.inverse()
     assert band_err(IB.get_images()[2], out[2]) <= 10 * tol
+
+
+def test_norm1_in_two_halves_and_clock_probe():
+    """Round-3 additions of the class / C-ABI: norm1_begin() + norm1_end() (enqueue, then read the double) equal norm1_f64(), with
+    and without the one-pass threshold shortcut; the in-kernel clock probe of the fused level kernels reports a plausible shader
+    clock for a double-precision level and nothing while it is off."""
+    import ctypes as C
+    x = np.random.RandomState(9).randn(512, 512)
+    for cache in (False, True):
+        W = pdwt_amd.Wavelets(x, "db20", 2, norm_cache=cache)
+        W.forward()
+        ref = W.norm1_f64()
+        Lh = W._L
+        Lh.pdwt_wavelets_norm1_begin.argtypes = [C.c_void_p]
+        Lh.pdwt_wavelets_norm1_end.argtypes = [C.c_void_p]
+        Lh.pdwt_wavelets_norm1_end.restype = C.c_double
+        Lh.pdwt_wavelets_norm1_begin(W._h)
+        assert Lh.pdwt_wavelets_norm1_end(W._h) == ref
+        W.soft_threshold(0.3)
+        Lh.pdwt_wavelets_norm1_begin(W._h)
+        assert abs(Lh.pdwt_wavelets_norm1_end(W._h) - W.norm1_f64()) <= 1e-12 * ref
+        assert Lh.pdwt_wavelets_norm1_end(W._h) == W.norm1_f64()  # end() without begin(): the one-call path
+    L = pdwt_amd.hip()
+    mhz, us = C.c_double(), C.c_double()
+    xb = np.random.RandomState(10).randn(4096, 4096)
+    Wb = pdwt_amd.Wavelets(xb, "db20", 1)
+    assert L.pdwt_clock_probe_enable(1) == 0
+    try:
+        Wb.forward()
+        Wb.inverse()
+        Wb.sync()
+        for slot in (2, 10):  # forward / inverse launches of the 4096-row size class
+            assert L.pdwt_clock_probe_read(slot, C.byref(mhz), C.byref(us)) == 0
+            assert 500.0 < mhz.value < 3500.0 and us.value > 1.0, (slot, mhz.value, us.value)
+    finally:
+        L.pdwt_clock_probe_enable(0)
+    assert L.pdwt_clock_probe_read(16, C.byref(mhz), C.byref(us)) != 0
