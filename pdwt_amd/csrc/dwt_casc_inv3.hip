@@ -458,7 +458,7 @@ static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* o
     const int strips = idiv_up(nc1, G::MAXVL * 2);
     const int VL = idiv_up(nc1 / 2, strips);
     int Wk = knob(KN_CASC_IWG);
-    if (Wk != 4 && Wk != 8 && Wk != 16) Wk = 16;
+    if (Wk != 4 && Wk != 8 && Wk != 12 && Wk != 16) Wk = 16;
     constexpr size_t REG = casc_inv3_region_bytes<HLEN>();
     auto lds_bytes = [&](int w) { return (size_t)(w - 1) * REG; };
     const int wgs = knob(KN_CASC_IWAVES) > 0 ? idiv_up(knob(KN_CASC_IWAVES), Wk) : 256;  // default: one workgroup per CU
@@ -476,7 +476,7 @@ static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* o
         return true;
     };
     int W = 0, gy = 0;
-    for (int w : {Wk, 16, 8, 4}) {
+    for (int w : {Wk, 16, 12, 8, 4}) {
         for (int g = std::max(1, wgs / strips); g >= std::max(1, wgs / strips / 2) && !W; g--)
             if (fits(w, g)) {
                 W = w;
@@ -490,9 +490,9 @@ static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* o
     const dim3 grid((unsigned)(8 * cm.cpx));
     const size_t lds = lds_bytes(W);
     void (*k)(CascInvBands, CascInv3B, float*, int, int, int, float*, CascMap, Taps2<float>);
-    k = (W == 4) ? k_inv2d_casc3<HLEN, 4, L3> : (W == 8) ? k_inv2d_casc3<HLEN, 8, L3> : k_inv2d_casc3<HLEN, 16, L3>;
+    k = (W == 4) ? k_inv2d_casc3<HLEN, 4, L3> : (W == 8) ? k_inv2d_casc3<HLEN, 8, L3> : (W == 12) ? k_inv2d_casc3<HLEN, 12, L3> : k_inv2d_casc3<HLEN, 16, L3>;
     if (lds > 64 * 1024) {  // opt-in once per (kernel, device), not per launch
-        const int rc = (W == 4) ? lds_opt_in<k_inv2d_casc3<HLEN, 4, L3>>() : (W == 8) ? lds_opt_in<k_inv2d_casc3<HLEN, 8, L3>>() : lds_opt_in<k_inv2d_casc3<HLEN, 16, L3>>();
+        const int rc = (W == 4) ? lds_opt_in<k_inv2d_casc3<HLEN, 4, L3>>() : (W == 8) ? lds_opt_in<k_inv2d_casc3<HLEN, 8, L3>>() : (W == 12) ? lds_opt_in<k_inv2d_casc3<HLEN, 12, L3>>() : lds_opt_in<k_inv2d_casc3<HLEN, 16, L3>>();
         if (rc != PDWT_OK) return rc;
     }
     KTimer kt(K_INV2D_CASC, true);
