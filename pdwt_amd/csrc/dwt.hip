@@ -863,6 +863,9 @@ static Batch2D* batch2d_create(int nimg, float* const* d_images, float** const* 
 {
     if (nimg < 1 || nimg > 65535 || !d_images || !d_coeffs || !d_tmps || w.ndims != 2 || w.do_swt || w.nlevels < 1 || w.nlevels > 32) return nullptr;
     if (force_twopass()) return nullptr;
+    // larger images belong to the cascade kernels, one image per launch (16 x 4096^2 db4 L3: 72.5 us per image there, 88.9 through
+    // the per-level kernels of this path; 32 x 2048^2: 31.0 against 23.7 here)
+    if ((long long)w.Nr * w.Nc > 2048LL * 2048) return nullptr;
     // every level must be inside the streaming path, in both directions
     int nr = w.Nr, nc = w.Nc;
     for (int lev = 0; lev < w.nlevels; lev++) {
