@@ -1194,3 +1194,30 @@ def test_norm1_in_two_halves_and_clock_probe():
     finally:
         L.pdwt_clock_probe_enable(0)
     assert L.pdwt_clock_probe_read(16, C.byref(mhz), C.byref(us)) != 0
+
+
+@pytest.mark.parametrize("wname", ["db2", "db4", "sym4"])
+def test_streamed_inverse_cascade_variants(wname):
+    """dwt_casc_inv3.hip (three inverse levels per launch, all streamed; also its two-level form): every workgroup shape (4 / 8 / 12 /
+    16 waves), depths 2-5 (L = 2, 4: two-level launches; L = 3, 5: the three-level launch first), wide / tall / minimal shapes,
+    against one launch per level -- bit for bit -- and the prologue form of dwt_casc_invw.hip (casc_l3 = 2)."""
+    rs = np.random.RandomState(5)
+    for (nr, nc) in ((2048, 2048), (4096, 1024), (1024, 4096), (2056, 2312), (512, 3072)):
+        x = rs.uniform(-50, 50, (nr, nc)).astype(np.float32)
+        for lev in (2, 3, 4, 5):
+            if nr % (1 << lev) or nc % (1 << lev):
+                continue
+            with knobs(casc=0, casc_min=0):
+                R = pdwt_amd.Wavelets(x, wname, lev)
+                R.forward()
+                ref_c = R.coeffs
+                R.inverse()
+                ref_i = R.get_image()
+            for kn in (dict(), dict(casc_iwg=4), dict(casc_iwg=8), dict(casc_iwg=12), dict(casc_l3=2)):
+                with knobs(casc_min=0, **kn):
+                    W = pdwt_amd.Wavelets(x, wname, lev)
+                    W.forward()
+                    for k, (a, b) in enumerate(zip(W.coeffs, ref_c)):
+                        assert np.array_equal(a, b), (wname, nr, nc, lev, kn, "band", k)
+                    W.inverse()
+                    assert np.array_equal(W.get_image(), ref_i), (wname, nr, nc, lev, kn)
