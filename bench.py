@@ -295,7 +295,7 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
     gpu_ms = L.pdwt_event_elapsed_ms(e0, e1)
     power = _SAMPLER.window(wall0, wall1) if _SAMPLER is not None else None
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -639,12 +639,19 @@ def main():
     import torch.distributed as dist
     pdwt_amd = pdwt_amd_mod()
 
+    # PDWT_BENCH_ONE_GPU=1 (test hook, with PDWT_BENCH_BACKEND=gloo): all ranks on device 0, so that the N > 1 code path of this
+    # file can be exercised on a 1-GPU box (tests/test_batch_gpu.py); the driver's runs use one GPU per rank over RCCL
+    if os.environ.get("PDWT_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     L = pdwt_amd.hip()
     assert L.pdwt_set_device(local_rank) == 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if os.environ.get("PDWT_BENCH_BACKEND", "nccl") == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     global _SAMPLER
     if rank == 0:

@@ -158,6 +158,25 @@ def test_one_rank_nccl_group_runs_the_rccl_branch():
     assert np.array_equal(img, W.get_image())
 
 
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_code_path_on_one_gpu():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with the two test hooks that let
+    it run on a 1-GPU box: both ranks on device 0 and gloo instead of RCCL.  Rank 0 must print ONE JSON line with n_gpus = 2, the
+    batch-split sanity values (norm1 all-reduce over 2 ranks) and a whole-job value."""
+    import json
+    import subprocess
+    env = dict(os.environ, PDWT_BENCH_ONE_GPU="1", PDWT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--cpu-seconds", "0", "--settle-ms", "20"], capture_output=True, text=True, timeout=580, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["other_configs"] is None
+    assert d["sanity"]["norm1_ranks"] == 2 and d["sanity"]["norm1_allreduce_rel_err"] <= 1e-12 and d["roundtrip_max_rel_err"] <= 1e-5
+
+
 @pytest.mark.parametrize("exe,shards", [("batch_demo", 3), ("batch_demod", 2), ("batch_demo", 8)])
 def test_one_process_batch_split_cpp(exe, shards):
     """include/wt_batch.h: the batch split driven from ONE host process through the C++ class (an instance per shard on
