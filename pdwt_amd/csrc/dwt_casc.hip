@@ -639,9 +639,14 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
             // (HLEN row registers in flight instead of HLEN/2 measured slower in this form too: 24.8 vs 24.6 us at W = 8)
             void (*k)(const float*, CascBands, int, int, int, float*, CascMap, TapsLH);
             k = (W == 4) ? k_fwd2d_casc<HLEN, NVD, 4> : (W == 8) ? k_fwd2d_casc<HLEN, NVD, 8> : k_fwd2d_casc<HLEN, NVD, 16>;
+            // 16 waves: TWO row registers per wave (one A1 row of prefetch) -- the launch starts with 8 instead of 10 rows per wave in flight
+            // (4032 waves: 33 instead of 41 MB of read-only start): C2 forward 23.5-23.8 -> 23.1-23.2 us (casc_nv = hlen/2: the round-2 depth)
+            const bool nv2 = W == 16 && (knob(KN_CASC_NV) == 0 || knob(KN_CASC_NV) == 2);
+            if (nv2) k = k_fwd2d_casc<HLEN, 2, 16>;
             if (lds > 64 * 1024) {  // opt-in once per (kernel, device), not per launch
-                const int rc = (W == 4) ? lds_opt_in<k_fwd2d_casc<HLEN, NVD, 4>>()
-                               : (W == 8) ? lds_opt_in<k_fwd2d_casc<HLEN, NVD, 8>>() : lds_opt_in<k_fwd2d_casc<HLEN, NVD, 16>>();
+                int rc = (W == 4) ? lds_opt_in<k_fwd2d_casc<HLEN, NVD, 4>>()
+                         : (W == 8) ? lds_opt_in<k_fwd2d_casc<HLEN, NVD, 8>>() : lds_opt_in<k_fwd2d_casc<HLEN, NVD, 16>>();
+                if (rc == PDWT_OK && nv2) rc = lds_opt_in<k_fwd2d_casc<HLEN, 2, 16>>();
                 if (rc != PDWT_OK) return rc;
             }
             PDWT_LAUNCH_KT(kt, k, grid, dim3(64 * W), lds, in, b, nr, nc, VL, trash, cm, f);
