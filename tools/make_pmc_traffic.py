@@ -42,13 +42,13 @@ write, _ = collect(wdir, "WRITE_SIZE")
 out_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 doc = json.load(open(out_path)) if os.path.exists(out_path) else {}
 import subprocess
-try:
-    doc["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+COMMIT = os.environ.get("PDWT_COMMIT", "")
+try:  # (the GPU box has no .git: the caller passes the commit in PDWT_COMMIT)
+    doc["commit"] = COMMIT or subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
 except Exception:
     pass
 doc["source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 10 --warmup 3`; "
                  "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the kernel's launches; summaries in profiles/*_pmc_*.md")
-COMMIT = os.environ.get("PDWT_COMMIT", "")
 sys.path.insert(0, ROOT)
 from bench import kernel_source_hash  # noqa: E402  (bench.py flags an entry whose hash differs from the sources it runs: traffic_stale)
 SRC = kernel_source_hash()
