@@ -138,6 +138,7 @@ enum KnobId {
     KN_SWTF_M,             // fused SWT forward: rows per chunk (0 = auto)
     KN_SWTF_MI,            // fused SWT inverse: rows per chunk (0 = auto)
     KN_SWTF_XCD,           // fused SWT levels: XCD-aware tile order
+    KN_SWTF_ALT,           // fused SWT inverse: neighbouring chunks of a residue class walk in opposite directions (shared rows out of L2)
     KN_SWTF_PERM,          // fused SWT inverse, tap spacing 4/8/16: residue-major LDS rows
     KN_SWTF_F64,           // 0: two-pass SWT in double precision instead of the fused per-level kernels
     KN_F64_LDS,            // LDS-ring form of the fused long double-precision level kernels (dwt_lds.hip)

@@ -56,7 +56,7 @@ static const KnobDef g_knob_defs[KN_COUNT] = {
     {"stream_narrow", "PDWT_STREAM_NARROW", 2048 * 2048}, {"small", "PDWT_SMALL", 1},
     {"rows_tr", "PDWT_ROWS_TR", 1}, {"ring_r", "PDWT_RING_R", 0}, {"ring_waves", "PDWT_RING_WAVES", 4096},
     {"swtf", "PDWT_SWTF", 1}, {"swtf_m", "PDWT_SWTF_M", 0}, {"swtf_mi", "PDWT_SWTF_MI", 0},
-    {"swtf_xcd", "PDWT_SWTF_XCD", 1}, {"swtf_perm", "PDWT_SWTF_PERM", 1}, {"swtf_f64", "PDWT_SWTF_F64", 1},
+    {"swtf_xcd", "PDWT_SWTF_XCD", 1}, {"swtf_alt", "PDWT_SWTF_ALT", 1}, {"swtf_perm", "PDWT_SWTF_PERM", 1}, {"swtf_f64", "PDWT_SWTF_F64", 1},
     {"f64_lds", "PDWT_F64_LDS", 1}, {"f64_lds_min", "PDWT_F64_LDS_MIN", 256}, {"f64_lds_wgs", "PDWT_F64_LDS_WGS", 512}, {"f64_lds_mingroups", "PDWT_F64_LDS_MINGROUPS", 1}, {"f64_lds_skew", "PDWT_F64_LDS_SKEW", 64}, {"norm2sq_ref1d", "PDWT_NORM2SQ_REF1D", 0},
     {"norm_in_threshold", "PDWT_NORM_IN_THRESHOLD", -1},
 };

@@ -175,6 +175,20 @@ template <int N, typename V>
 __device__ __forceinline__ void asm_wait4(V& a, V& b, V& c, V& d) { asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory"); }
 template <int N, typename V>
 __device__ __forceinline__ void asm_wait3(V& a, V& b, V& c) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory"); }
+// Counted wait chosen at run time inside ONE asm statement: `counted` (uniform) ? vmcnt(N) : vmcnt(0).  An if / else around two tied
+// waits makes the load registers PHI values, and hipcc may then copy a register whose load is still in flight.
+template <int N, typename V>
+__device__ __forceinline__ void asm_wait2_sel(bool counted, V& a, V& b)
+{
+    asm volatile("s_cmp_eq_u32 %2, 0\n\ts_cbranch_scc1 .Lws0_%=\n\ts_waitcnt vmcnt(%3)\n\ts_branch .Lws1_%=\n.Lws0_%=:\n\ts_waitcnt vmcnt(0)\n.Lws1_%=:"
+                 : "+v"(a), "+v"(b) : "s"(__builtin_amdgcn_readfirstlane((int)counted)), "n"(N) : "memory", "scc");
+}
+template <int N, typename V>
+__device__ __forceinline__ void asm_wait8_sel(bool counted, V& a, V& b, V& c, V& d, V& e, V& f, V& g, V& h)
+{
+    asm volatile("s_cmp_eq_u32 %8, 0\n\ts_cbranch_scc1 .Lws0_%=\n\ts_waitcnt vmcnt(%9)\n\ts_branch .Lws1_%=\n.Lws0_%=:\n\ts_waitcnt vmcnt(0)\n.Lws1_%=:"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "s"(__builtin_amdgcn_readfirstlane((int)counted)), "n"(N) : "memory", "scc");
+}
 template <typename V>
 __device__ __forceinline__ void asm_drain1(V& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) : : "memory"); }
 
