@@ -3,6 +3,14 @@
 #pragma once
 #include "common.hpp"
 
+// diagnostic builds only (tools/casc_diag.sh): PDWT_CASC_DIAG & 1 folds every stored row, & 2 every loaded row onto 32 rows of its
+// array (L2-resident): the results are wrong, the timings say what the cascade kernels cost without their memory traffic
+#ifndef PDWT_CASC_DIAG
+#define PDWT_CASC_DIAG 0
+#endif
+#define CASC_DIAG_ST(row) ((PDWT_CASC_DIAG & 1) ? ((row) & 31) : (row))
+#define CASC_DIAG_LD(row) ((PDWT_CASC_DIAG & 2) ? ((row) & 31) : (row))
+
 namespace pdwt {
 
 template <int HLEN>

@@ -124,9 +124,9 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
     for (int k = 0; k < HLEN; k++) ring2[k] = v2f{0.f, 0.f};
 
     const float* const lbase = in + xo;
-    auto rowptr = [&](int r) { return lbase + (size_t)wrap1(yb + r, Nr) * Nc; };
+    auto rowptr = [&](int r) { return lbase + (size_t)CASC_DIAG_LD(wrap1(yb + r, Nr)) * Nc; };
     // steady state: uniform row base on the scalar unit + loop-invariant per-lane byte offset (stream_dev.hpp)
-    auto rowbase = [&](int r) { return in + (size_t)wrap1(yb + r, Nr) * Nc; };
+    auto rowbase = [&](int r) { return in + (size_t)CASC_DIAG_LD(wrap1(yb + r, Nr)) * Nc; };
     const unsigned xoff = (unsigned)xo * 4u;
 
     // hand-off area: region kw is READ by this wave (written by wave kw+1), region kw-1 is WRITTEN by it
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                 {
                     // rows the wave does not own (the recomputed halo) go to the trash rows (uniform select on the scalar unit)
                     const bool own = n < NA;
-                    const size_t o = (size_t)wrap1(2 * j0 + n - C, Nr2) * Nc2;
+                    const size_t o = (size_t)CASC_DIAG_ST(wrap1(2 * j0 + n - C, Nr2)) * Nc2;
                     asm_store_sm(own ? b.H1 + o : tr, off1, v2f{ah[0].y, ah[1].y}, vmask);
                     asm_store_sm(own ? b.V1 + o : tr, off1, v2f{vd[0].x, vd[1].x}, vmask);
                     asm_store_sm(own ? b.D1 + o : tr, off1, v2f{vd[0].y, vd[1].y}, vmask);
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                 });
                 const int jl = (n - (HLEN - 1)) >> 1;
                 const bool own = (n >= HLEN - 1) && (jl < rows2);
-                const size_t o = (size_t)(j0 + jl) * Nc4;
+                const size_t o = (size_t)CASC_DIAG_ST(j0 + jl) * Nc4;
                 asm_store_sm(own ? b.A2 + o : tr, off2, ah2.x, vmask);
                 asm_store_sm(own ? b.H2 + o : tr, off2, ah2.y, vmask);
                 asm_store_sm(own ? b.V2 + o : tr, off2, vd2.x, vmask);

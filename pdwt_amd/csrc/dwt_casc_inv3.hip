@@ -95,9 +95,9 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     const int bp_addr = 4 * (((X0 + lane + 1) >> 1) - ((X0 + 1) >> 1) + C);
     const bool bp_odd = ((X0 + lane) & 1) != 0;
 
-    auto off3 = [&](int i) { return (size_t)wrapi(P3_0 - C + i, Nr3) * Nc3; };
-    auto off2 = [&](int s2) { return (size_t)wrap1(Q0 + s2, Nr2) * Nc2; };
-    auto off1 = [&](int r1) { return (size_t)wrap1(P0 + r1, Nr1) * Nc1; };
+    auto off3 = [&](int i) { return (size_t)CASC_DIAG_LD(wrapi(P3_0 - C + i, Nr3)) * Nc3; };
+    auto off2 = [&](int s2) { return (size_t)CASC_DIAG_LD(wrap1(Q0 + s2, Nr2)) * Nc2; };
+    auto off1 = [&](int r1) { return (size_t)CASC_DIAG_LD(wrap1(P0 + r1, Nr1)) * Nc1; };
     const unsigned voff3 = (unsigned)c3w * 4u, voff2 = (unsigned)cx2w * 4u, voff1 = (unsigned)cx1w * 4u, voffo = (unsigned)(valid ? cx1 : 0) * 8u;
     const lanemask_t vmask = __ballot(valid);
 
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
             const v2f pb = nat_pair(t1w + 1, t2w + 1);  // outputs 2 c0 + 3, 2 c0 + 4 (the second belongs to the lane to the right)
             o4 = v4f{dpp_shr1(pb.y), pa.x, pa.y, pb.x};
         }
-        asm_store_sm(own ? out + (size_t)wrap1(O0 + g, Nr) * Nc : tr, voffo, o4, vmask);
+        asm_store_sm(own ? out + (size_t)CASC_DIAG_ST(wrap1(O0 + g, Nr)) * Nc : tr, voffo, o4, vmask);
     };
 
     auto step = [&](auto Pp, int sb) {

@@ -155,6 +155,13 @@ __device__ __forceinline__ void asm_store_sm(float* sbase, unsigned voff, v4f d,
     asm volatile("s_and_saveexec_b64 %0, %4\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_nop 1\n\ts_mov_b64 exec, %0"
                  : "=&s"(saved) : "v"(voff), "v"(d), "s"(sbase), "s"(mask) : "memory", "scc");
 }
+// the same with the non-temporal hint (streaming data nobody reads soon: the detail bands of an SWT level)
+__device__ __forceinline__ void asm_store_sm_nt(float* sbase, unsigned voff, v4f d, lanemask_t mask)
+{
+    lanemask_t saved;
+    asm volatile("s_and_saveexec_b64 %0, %4\n\tglobal_store_dwordx4 %1, %2, %3 nt\n\ts_nop 1\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(voff), "v"(d), "s"(sbase), "s"(mask) : "memory", "scc");
+}
 // Opaque register copies out of a load register.  A plain C++ copy may be coalesced with its source; the tied
 // load that follows would then be given a fresh register and the loop back-edge a v_mov of the in-flight one.
 __device__ __forceinline__ float asm_copy(const float& src)
