@@ -124,9 +124,9 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
     for (int k = 0; k < HLEN; k++) ring2[k] = v2f{0.f, 0.f};
 
     const float* const lbase = in + xo;
-    auto rowptr = [&](int r) { return lbase + (size_t)CASC_DIAG_LD(wrap1(yb + r, Nr)) * Nc; };
+    auto rowptr = [&](int r) { return lbase + (size_t)wrap1(yb + r, Nr) * Nc; };
     // steady state: uniform row base on the scalar unit + loop-invariant per-lane byte offset (stream_dev.hpp)
-    auto rowbase = [&](int r) { return in + (size_t)CASC_DIAG_LD(wrap1(yb + r, Nr)) * Nc; };
+    auto rowbase = [&](int r) { return in + (size_t)wrap1(yb + r, Nr) * Nc; };
     const unsigned xoff = (unsigned)xo * 4u;
 
     // hand-off area: region kw is READ by this wave (written by wave kw+1), region kw-1 is WRITTEN by it
@@ -198,9 +198,37 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
         }
     }
 
-    float* const tr = trash + (size_t)(blockIdx.x & 15) * Nc2;  // a trash ROW (the dispatcher checks the area holds 16 of them)
     const unsigned off1 = (unsigned)(valid ? x >> 1 : 0) * 4u, off2 = (unsigned)(valid ? x >> 2 : 0) * 4u;
     const lanemask_t vmask = __ballot(valid);
+    // Scalar bookkeeping.  The scalar unit, not the vector ALUs or memory, bounds this kernel (40 extra scalar instructions per A1 row:
+    // +3.5 us at C2; 20 extra vector instructions: +0.75), so nothing per row is recomputed from indices:
+    //  * loads walk consecutive rows: a 64-bit row pointer advanced by the row stride (reset at the image's last row, frozen at the
+    //    wave's last row), instead of wrap + 64-bit multiply per load;
+    //  * stores take the band base (loop-invariant SGPR pair) and a per-lane offset = lane offset + 32-bit row offset (one v_add per
+    //    row; the host sends images whose level-1 bands exceed 4 GiB to the level kernels), the row offsets advance by the band's row
+    //    stride; rows the wave does not own are stored with EXEC = 0 (no trash row, no select per band);
+    //  * the three / four stores of a row share one exec save / restore (asm_store3_sm / asm_store4_sm).
+    const int lim1 = ((W == 1) || last) ? 0x7fffffff : NL1;  // A1 rows below lim1 take their input rows from memory ...
+    const int lim2 = ((W == 1) || last) ? 0x7fffffff : NA;   // ... below lim2 they are computed here
+    int lr = HLEN - 2 + NV;                                   // chunk-local input row of the next prefetch
+    int lgr = wrap1(yb + min(lr, rlast), Nr);                 // its image row
+    const float* lp = in + (size_t)lgr * Nc;
+    auto next_row = [&]() {  // row pointer of the next prefetch; moves on unless the wave's last row is reached
+        const float* p = lp;
+        if (lr < rlast) {
+            lp += Nc;
+            if (++lgr == Nr) {
+                lgr = 0;
+                lp = in;
+            }
+        }
+        lr++;
+        return p;
+    };
+    int s1row = wrap1(2 * j0 - C, Nr2);                       // level-1 row of A1 row 0
+    unsigned s1off = (unsigned)s1row * (unsigned)Nc2 * 4u;    // ... its byte offset inside a level-1 band
+    unsigned s2off = (unsigned)j0 * (unsigned)Nc4 * 4u;       // byte offset of the wave's next own level-2 row
+    (void)trash;
     CASC_TRACE(1);  // ring prologue computed (its loads landed)
     static_for<NV>([&](auto K) { asm_drain1(v[decltype(K)::value]); });
     CASC_TRACE(2);  // first body's rows landed
@@ -210,8 +238,8 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
             constexpr int s0 = (2 * u + HLEN - 2) % HLEN, s1 = (2 * u + HLEN - 1) % HLEN;
             const int n = sb * HLEN + a;  // chunk-local A1 row
             constexpr int r0 = (2 * a) % NV, r1 = r0 + 1;
-            const bool mem1 = (W == 1) || last || (n < NL1);   // the two new input rows come from memory
-            const bool comp = (W == 1) || last || (n < NA);    // the A1 row is computed here
+            const bool mem1 = n < lim1;   // the two new input rows come from memory
+            const bool comp = n < lim2;   // the A1 row is computed here
             if (mem1) {
                 // v[r0], v[r1] were loaded DIST A1 rows ago, at position (a - DIST) mod HLEN
                 asm_wait2<casc_fwd_after<DIST>((a + HLEN - DIST) % HLEN)>(v[r0], v[r1]);
@@ -228,10 +256,10 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                 }
             }
             if (comp) {
-                const int rn = 2 * n + HLEN - 2 + NV;  // the rows these registers hold DIST A1 rows ahead
-                // (clamped to the wave's last row: the prefetch past the end re-reads a cached line instead of fetching new ones)
-                asm_load_s(v[r0], rowbase(min(rn, rlast)), xoff);
-                asm_load_s(v[r1], rowbase(min(rn + 1, rlast)), xoff);
+                // rows 2n + HLEN-2 + NV and the next one, DIST A1 rows ahead (frozen at the wave's last row: the prefetch past the end
+                // re-reads a cached line instead of fetching new ones)
+                asm_load_s(v[r0], next_row(), xoff);
+                asm_load_s(v[r1], next_row(), xoff);
                 // level-1 column pass
                 v2f ah[2], vd[2];
 #pragma unroll
@@ -247,12 +275,14 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                     }
                 });
                 {
-                    // rows the wave does not own (the recomputed halo) go to the trash rows (uniform select on the scalar unit)
-                    const bool own = n < NA;
-                    const size_t o = (size_t)CASC_DIAG_ST(wrap1(2 * j0 + n - C, Nr2)) * Nc2;
-                    asm_store_sm(own ? b.H1 + o : tr, off1, v2f{ah[0].y, ah[1].y}, vmask);
-                    asm_store_sm(own ? b.V1 + o : tr, off1, v2f{vd[0].x, vd[1].x}, vmask);
-                    asm_store_sm(own ? b.D1 + o : tr, off1, v2f{vd[0].y, vd[1].y}, vmask);
+                    // rows the wave does not own (the recomputed halo) are stored with every lane off
+                    asm_store3_sm(b.H1, b.V1, b.D1, off1 + s1off, v2f{ah[0].y, ah[1].y}, v2f{vd[0].x, vd[1].x}, v2f{vd[0].y, vd[1].y},
+                                  n < NA ? vmask : 0ull);
+                    s1off += (unsigned)Nc2 * 4u;
+                    if (++s1row == Nr2) {
+                        s1row = 0;
+                        s1off = 0;
+                    }
                 }
                 // level-2 row pass on the A1 pair; ring2 slot = n % HLEN = a
                 row_pass2(ah[0].x, ah[1].x, ring2[a]);
@@ -273,13 +303,9 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                     ah2 = pk_fma(splat(ring2[s].x), t, ah2);
                     vd2 = pk_fma(splat(ring2[s].y), t, vd2);
                 });
-                const int jl = (n - (HLEN - 1)) >> 1;
-                const bool own = (n >= HLEN - 1) && (jl < rows2);
-                const size_t o = (size_t)CASC_DIAG_ST(j0 + jl) * Nc4;
-                asm_store_sm(own ? b.A2 + o : tr, off2, ah2.x, vmask);
-                asm_store_sm(own ? b.H2 + o : tr, off2, ah2.y, vmask);
-                asm_store_sm(own ? b.V2 + o : tr, off2, vd2.x, vmask);
-                asm_store_sm(own ? b.D2 + o : tr, off2, vd2.y, vmask);
+                const bool own = (n >= HLEN - 1) && (n < HLEN - 1 + 2 * rows2);  // level-2 row (n - (HLEN-1)) / 2 of the wave's rows2
+                asm_store4_sm(b.A2, b.H2, b.V2, b.D2, off2 + s2off, ah2.x, ah2.y, vd2.x, vd2.y, own ? vmask : 0ull);
+                s2off += own ? (unsigned)Nc4 * 4u : 0u;
             }
     };
     for (int sb = 0;; sb++) {
@@ -683,6 +709,7 @@ int fwd2d_casc_f32(const float* in, float* H1, float* V1, float* D1, float* A2, 
     if (!casc_enabled() || !stream_enabled() || !trash) return 1;
     if ((nr & 3) || (nc & 3) || nc < 256 || nr < 16 * hlen) return 1;
     if ((long long)nr * nc < (long long)knob(KN_CASC_MIN)) return 1;
+    if ((long long)nr * nc >= (1LL << 32)) return 1;  // 32-bit row offsets inside a level-1 band (nr/2 x nc/2 floats): the level kernels take larger images
     if (!al16(in) || !al16(H1) || !al16(V1) || !al16(D1) || !al16(A2) || !al16(H2) || !al16(V2) || !al16(D2)) return 1;
     const CascBands b = {H1, V1, D1, A2, H2, V2, D2};
     switch (hlen) {

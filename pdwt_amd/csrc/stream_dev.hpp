@@ -155,6 +155,21 @@ __device__ __forceinline__ void asm_store_sm(float* sbase, unsigned voff, v4f d,
     asm volatile("s_and_saveexec_b64 %0, %4\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_nop 1\n\ts_mov_b64 exec, %0"
                  : "=&s"(saved) : "v"(voff), "v"(d), "s"(sbase), "s"(mask) : "memory", "scc");
 }
+// Several masked stores under ONE exec save / restore (2 scalar instructions per group instead of 2 per store; the scalar unit is what
+// bounds the cascade kernels).  mask == 0 is allowed: the stores then write nothing but still count in vmcnt, in order
+// (tools/probes/vmcnt_order.hip), so rows a wave does not own need neither a trash row nor a pointer select.
+__device__ __forceinline__ void asm_store3_sm(float* b0, float* b1, float* b2, unsigned voff, v2f d0, v2f d1, v2f d2, lanemask_t mask)
+{
+    lanemask_t saved;
+    asm volatile("s_and_saveexec_b64 %0, %8\n\tglobal_store_dwordx2 %1, %2, %5\n\tglobal_store_dwordx2 %1, %3, %6\n\tglobal_store_dwordx2 %1, %4, %7\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(voff), "v"(d0), "v"(d1), "v"(d2), "s"(b0), "s"(b1), "s"(b2), "s"(mask) : "memory", "scc");
+}
+__device__ __forceinline__ void asm_store4_sm(float* b0, float* b1, float* b2, float* b3, unsigned voff, float d0, float d1, float d2, float d3, lanemask_t mask)
+{
+    lanemask_t saved;
+    asm volatile("s_and_saveexec_b64 %0, %10\n\tglobal_store_dword %1, %2, %6\n\tglobal_store_dword %1, %3, %7\n\tglobal_store_dword %1, %4, %8\n\tglobal_store_dword %1, %5, %9\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(voff), "v"(d0), "v"(d1), "v"(d2), "v"(d3), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(mask) : "memory", "scc");
+}
 // the same with the non-temporal hint (streaming data nobody reads soon: the detail bands of an SWT level)
 __device__ __forceinline__ void asm_store_sm_nt(float* sbase, unsigned voff, v4f d, lanemask_t mask)
 {
@@ -189,6 +204,13 @@ __device__ __forceinline__ void asm_wait2_sel(bool counted, V& a, V& b)
 {
     asm volatile("s_cmp_eq_u32 %2, 0\n\ts_cbranch_scc1 .Lws0_%=\n\ts_waitcnt vmcnt(%3)\n\ts_branch .Lws1_%=\n.Lws0_%=:\n\ts_waitcnt vmcnt(0)\n.Lws1_%=:"
                  : "+v"(a), "+v"(b) : "s"(__builtin_amdgcn_readfirstlane((int)counted)), "n"(N) : "memory", "scc");
+}
+// ... and with two counts: `first` (uniform) ? vmcnt(NF) : vmcnt(NS)
+template <int NF, int NS, typename V>
+__device__ __forceinline__ void asm_wait2_sel2(bool first, V& a, V& b)
+{
+    asm volatile("s_cmp_eq_u32 %2, 0\n\ts_cbranch_scc1 .Lwt0_%=\n\ts_waitcnt vmcnt(%3)\n\ts_branch .Lwt1_%=\n.Lwt0_%=:\n\ts_waitcnt vmcnt(%4)\n.Lwt1_%=:"
+                 : "+v"(a), "+v"(b) : "s"(__builtin_amdgcn_readfirstlane((int)first)), "n"(NF), "n"(NS) : "memory", "scc");
 }
 template <int N, typename V>
 __device__ __forceinline__ void asm_wait8_sel(bool counted, V& a, V& b, V& c, V& d, V& e, V& f, V& g, V& h)

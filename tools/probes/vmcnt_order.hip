@@ -11,7 +11,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float fval(size_t i) { return (float)(i % 1000003u); }
 
-template <int NST, bool COUNTED>
+template <int NST, bool COUNTED, bool EXEC0 = false>
 __global__ __launch_bounds__(256) void k(const float* __restrict__ tab, size_t n4, float* sink, size_t sink4, int steps, unsigned long long* bad)
 {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
@@ -39,6 +39,10 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ tab, size_t n
 #pragma unroll
         for (int q = 0; q < NST; q++) {
             float* p = sink + 4 * ((gid + (size_t)(s * NST + q) * nthr) % sink4);
+            if (EXEC0) {
+                unsigned long long saved, zero = (s & 1) ? 0ull : ~0ull;  // every second step: all lanes off
+                asm volatile("s_and_saveexec_b64 %0, %3\n\tglobal_store_dwordx4 %1, %2, off\n\ts_nop 1\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(p), "v"(o), "s"(zero) : "memory", "scc");
+            } else
             asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(o) : "memory");
         }
     }
@@ -81,5 +85,7 @@ int main()
     run("vmcnt(1), 1 store  -> 1 MB", k<1, true>, sink_small, (1 << 20) / 16);
     run("vmcnt(1), 1 store  -> 2 GB", k<1, true>, sink_big, ((size_t)2 << 30) / 16);
     run("vmcnt(0), 4 stores -> 2 GB", k<4, false>, sink_big, ((size_t)2 << 30) / 16);
+    run("vmcnt(4), 4 stores, EXEC = 0 every 2nd step", k<4, true, true>, sink_big, ((size_t)2 << 30) / 16);
+    run("vmcnt(1), 1 store,  EXEC = 0 every 2nd step", k<1, true, true>, sink_small, (1 << 20) / 16);
     return 0;
 }
