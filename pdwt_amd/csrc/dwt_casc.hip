@@ -210,25 +210,38 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
     //  * the three / four stores of a row share one exec save / restore (asm_store3_sm / asm_store4_sm).
     const int lim1 = ((W == 1) || last) ? 0x7fffffff : NL1;  // A1 rows below lim1 take their input rows from memory ...
     const int lim2 = ((W == 1) || last) ? 0x7fffffff : NA;   // ... below lim2 they are computed here
-    int lr = HLEN - 2 + NV;                                   // chunk-local input row of the next prefetch
+    // prefetch cursor: rows come in pairs (even, odd chunk-local row; rlast is odd, so a pair is either two new rows or -- past the
+    // wave's last row -- twice that row, a cached re-read); the image wrap (at most once per wave) takes the slow branch
+    int lr = HLEN - 2 + NV;                                   // chunk-local row of the next pair (even)
     int lgr = wrap1(yb + min(lr, rlast), Nr);                 // its image row
     const float* lp = in + (size_t)lgr * Nc;
-    auto next_row = [&]() {  // row pointer of the next prefetch; moves on unless the wave's last row is reached
-        const float* p = lp;
-        if (lr < rlast) {
-            lp += Nc;
-            if (++lgr == Nr) {
-                lgr = 0;
-                lp = in;
+    const float* lplast = lp;                                 // the last row fetched (what a frozen pair re-reads)
+    const size_t strideF = (size_t)Nc;
+    auto next_rows = [&](const float*& p0, const float*& p1) {
+        int lrq = lr;
+        asm("" : "+s"(lrq));  // (a compare of its own: hipcc otherwise keeps the predicate as a lane mask, 3 scalar instructions per use)
+        if (lrq < rlast) {
+            p0 = lp;
+            if (lgr + 2 < Nr) {
+                p1 = lp + strideF;
+                lp = p1 + strideF;
+                lgr += 2;
+            } else {
+                p1 = (lgr + 1 == Nr) ? in : lp + strideF;
+                lgr = (lgr + 2 >= Nr) ? lgr + 2 - Nr : lgr + 2;
+                lp = in + (size_t)lgr * Nc;
             }
+            lplast = p1;
+        } else {
+            p0 = p1 = lplast;
         }
-        lr++;
-        return p;
+        lr += 2;
     };
-    int s1row = wrap1(2 * j0 - C, Nr2);                       // level-1 row of A1 row 0
-    unsigned s1off = (unsigned)s1row * (unsigned)Nc2 * 4u;    // ... its byte offset inside a level-1 band
+    unsigned s1off = (unsigned)wrap1(2 * j0 - C, Nr2) * (unsigned)Nc2 * 4u;  // byte offset of the level-1 row of A1 row 0 inside a band
+    const unsigned s1end = (unsigned)Nr2 * (unsigned)Nc2 * 4u;               // (bands of 4 GiB and more never get here)
     unsigned s2off = (unsigned)j0 * (unsigned)Nc4 * 4u;       // byte offset of the wave's next own level-2 row
     (void)trash;
+    const int hand_sb = __builtin_amdgcn_readfirstlane((W > 1 && kw > 0) ? 0 : -1);  // the super-body in which the ring2 rows are handed up
     CASC_TRACE(1);  // ring prologue computed (its loads landed)
     static_for<NV>([&](auto K) { asm_drain1(v[decltype(K)::value]); });
     CASC_TRACE(2);  // first body's rows landed
@@ -238,28 +251,35 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
             constexpr int s0 = (2 * u + HLEN - 2) % HLEN, s1 = (2 * u + HLEN - 1) % HLEN;
             const int n = sb * HLEN + a;  // chunk-local A1 row
             constexpr int r0 = (2 * a) % NV, r1 = r0 + 1;
-            const bool mem1 = n < lim1;   // the two new input rows come from memory
-            const bool comp = n < lim2;   // the A1 row is computed here
-            if (mem1) {
-                // v[r0], v[r1] were loaded DIST A1 rows ago, at position (a - DIST) mod HLEN
-                asm_wait2<casc_fwd_after<DIST>((a + HLEN - DIST) % HLEN)>(v[r0], v[r1]);
-                row_pass1(v[r0], ring[s0]);
-                row_pass1(v[r1], ring[s1]);
-            } else if (comp) {
-                if constexpr (W > 1) {  // ... or from the wave below (its ring warm-up rows)
-                    const int i0 = 2 * (n - NL1);
-                    const v4f q0 = *lds_ring(lds_rd, i0), q1 = *lds_ring(lds_rd, i0 + 1);
-                    ring[s0][0] = v2f{q0.x, q0.y};
-                    ring[s0][1] = v2f{q0.z, q0.w};
-                    ring[s1][0] = v2f{q1.x, q1.y};
-                    ring[s1][1] = v2f{q1.z, q1.w};
+            // (every use of a predicate is a scalar compare of its own -- laundered copies of n: hipcc otherwise carries the predicates
+            // as lane masks from use to use, ~40 scalar instructions per A1 row)
+            int nq1 = n, nq2 = n;
+            asm("" : "+s"(nq1));
+            asm("" : "+s"(nq2));
+            if (nq2 < lim2) {  // the A1 row is computed here (a nested if / else tree: two sequential ifs made hipcc thread the cases through mask flags)
+                if (nq1 < lim1) {
+                    // its two new input rows come from memory: v[r0], v[r1] were loaded DIST A1 rows ago, at position (a - DIST) mod HLEN
+                    asm_wait2<casc_fwd_after<DIST>((a + HLEN - DIST) % HLEN)>(v[r0], v[r1]);
+                    row_pass1(v[r0], ring[s0]);
+                    row_pass1(v[r1], ring[s1]);
+                } else {
+                    if constexpr (W > 1) {  // ... or from the wave below (its ring warm-up rows)
+                        const int i0 = 2 * (n - NL1);
+                        const v4f q0 = *lds_ring(lds_rd, i0), q1 = *lds_ring(lds_rd, i0 + 1);
+                        ring[s0][0] = v2f{q0.x, q0.y};
+                        ring[s0][1] = v2f{q0.z, q0.w};
+                        ring[s1][0] = v2f{q1.x, q1.y};
+                        ring[s1][1] = v2f{q1.z, q1.w};
+                    }
                 }
-            }
-            if (comp) {
                 // rows 2n + HLEN-2 + NV and the next one, DIST A1 rows ahead (frozen at the wave's last row: the prefetch past the end
                 // re-reads a cached line instead of fetching new ones)
-                asm_load_s(v[r0], next_row(), xoff);
-                asm_load_s(v[r1], next_row(), xoff);
+                {
+                    const float *p0, *p1;
+                    next_rows(p0, p1);
+                    asm_load_s(v[r0], p0, xoff);
+                    asm_load_s(v[r1], p1, xoff);
+                }
                 // level-1 column pass
                 v2f ah[2], vd[2];
 #pragma unroll
@@ -279,16 +299,13 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                     asm_store3_sm(b.H1, b.V1, b.D1, off1 + s1off, v2f{ah[0].y, ah[1].y}, v2f{vd[0].x, vd[1].x}, v2f{vd[0].y, vd[1].y},
                                   n < NA ? vmask : 0ull);
                     s1off += (unsigned)Nc2 * 4u;
-                    if (++s1row == Nr2) {
-                        s1row = 0;
-                        s1off = 0;
-                    }
+                    if (s1off == s1end) s1off = 0;
                 }
                 // level-2 row pass on the A1 pair; ring2 slot = n % HLEN = a
                 row_pass2(ah[0].x, ah[1].x, ring2[a]);
                 if constexpr (W > 1 && a < HLEN - 2) {
                     // first super-body: the wave above needs the row-pass results of this wave's first HLEN-2 A1 rows
-                    if (sb == 0 && kw > 0) *lds_ring2(lds_wr, a) = ring2[a];
+                    if (sb == hand_sb) *lds_ring2(lds_wr, a) = ring2[a];  // (sb == 0 and not the first wave)
                 }
             } else {
                 if constexpr (W > 1) ring2[a] = *lds_ring2(lds_rd, min(n - NA, HLEN - 3));
