@@ -12,8 +12,9 @@
 // Halo: NB1 lanes (input) + NB2 lanes (A1) per side -> 58 producing lanes of 64 for hlen 8; vertically a
 // chunk of level-(l+1) rows recomputes hlen-2 rows of A1 (and re-reads 3(hlen-2) input rows).
 // The loop issues every store unconditionally: lanes that own no output are masked through EXEC, rows
-// outside the chunk's own range and the ring warm-up go to a trash row (a scalar select of the base), so the
-// hand-counted s_waitcnt pipeline of dwt_stream.hip carries over with per-position constants (casc_fwd_after).
+// outside the chunk's own range and the ring warm-up are stored with EXEC = 0 (forward; they still count in vmcnt, in order:
+// tools/probes/vmcnt_order.hip) or go to a trash row (inverse), so the hand-counted s_waitcnt pipeline of
+// dwt_stream.hip carries over with per-position constants (casc_fwd_after).
 // Arithmetic per sample = the single-level kernels' (row pass then column pass, taps ascending, one FMA
 // per tap), so the result is bit-identical to running the two levels separately.
 // Reference code replaced: two iterations of the level loop of w_forward_separable / w_inverse_separable

@@ -205,13 +205,6 @@ __device__ __forceinline__ void asm_wait2_sel(bool counted, V& a, V& b)
     asm volatile("s_cmp_eq_u32 %2, 0\n\ts_cbranch_scc1 .Lws0_%=\n\ts_waitcnt vmcnt(%3)\n\ts_branch .Lws1_%=\n.Lws0_%=:\n\ts_waitcnt vmcnt(0)\n.Lws1_%=:"
                  : "+v"(a), "+v"(b) : "s"(__builtin_amdgcn_readfirstlane((int)counted)), "n"(N) : "memory", "scc");
 }
-// ... and with two counts: `first` (uniform) ? vmcnt(NF) : vmcnt(NS)
-template <int NF, int NS, typename V>
-__device__ __forceinline__ void asm_wait2_sel2(bool first, V& a, V& b)
-{
-    asm volatile("s_cmp_eq_u32 %2, 0\n\ts_cbranch_scc1 .Lwt0_%=\n\ts_waitcnt vmcnt(%3)\n\ts_branch .Lwt1_%=\n.Lwt0_%=:\n\ts_waitcnt vmcnt(%4)\n.Lwt1_%=:"
-                 : "+v"(a), "+v"(b) : "s"(__builtin_amdgcn_readfirstlane((int)first)), "n"(NF), "n"(NS) : "memory", "scc");
-}
 template <int N, typename V>
 __device__ __forceinline__ void asm_wait8_sel(bool counted, V& a, V& b, V& c, V& d, V& e, V& f, V& g, V& h)
 {
