@@ -1221,3 +1221,56 @@ def test_streamed_inverse_cascade_variants(wname):
                         assert np.array_equal(a, b), (wname, nr, nc, lev, kn, "band", k)
                     W.inverse()
                     assert np.array_equal(W.get_image(), ref_i), (wname, nr, nc, lev, kn)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname", ["db2", "db7", "sym8"])
+def test_fused_swt_inverse_walk_directions_and_chunk_heights(wname):
+    """swt_fused.inc, inverse levels: chunks of a residue class walk in alternating directions by default (swtf_alt = 1: the rows two
+    neighbours share come out of the XCD's L2).  An upward chunk sums its column taps bottom-up, so the two orders agree to rounding, not
+    bit for bit: both are checked against the two-pass kernels (swtf = 0) at 1e-5 relative, over chunk heights that put the direction
+    change at different rows, odd chunk counts (the last chunk alone) and tiles narrower than a workgroup's 1024 columns."""
+    rs = np.random.RandomState(11)
+    for (nr, nc, lev) in ((256, 1024, 3), (384, 2048, 2), (512, 640, 4), (1024, 1024, 5)):
+        x = rs.uniform(-1, 1, (nr, nc)).astype(np.float32)
+        with knobs(swtf=0):
+            R = pdwt_amd.Wavelets(x, wname, lev, do_swt=1)
+            R.forward()
+            ref_c = R.coeffs
+            R.inverse()
+            ref_i = R.get_image()
+        scale = float(np.abs(ref_i).max())
+        for kn in (dict(), dict(swtf_alt=0), dict(swtf_mi=14), dict(swtf_mi=23), dict(swtf_mi=40, swtf_alt=1), dict(swtf_m=17)):
+            with knobs(**kn):
+                W = pdwt_amd.Wavelets(x, wname, lev, do_swt=1)
+                W.forward()
+                for k, (a, b) in enumerate(zip(W.coeffs, ref_c)):
+                    assert np.array_equal(a, b), (wname, nr, nc, lev, kn, "band", k)  # forward: same summation order as two passes
+                W.inverse()
+                err = float(np.abs(W.get_image() - ref_i).max()) / scale
+                assert err <= 1e-5, (wname, nr, nc, lev, kn, err)
+                # and the reconstruction itself
+                assert float(np.abs(W.get_image() - x).max()) <= 2e-5 * max(1.0, scale), (wname, nr, nc, lev, kn)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wname", ["db2", "db4", "sym4"])
+def test_forward_cascade_row_cursors(wname):
+    """dwt_casc.hip, forward: the prefetch cursor (pairs of rows, frozen at a wave's last row, reset at the image's last row), the 32-bit
+    band row offsets and the EXEC = 0 stores of rows a wave does not own -- every workgroup shape (independent waves, 4 / 8 / 16 stacked
+    waves), both prefetch depths, chunk counts that put the image wrap in the first, a middle and the last workgroup; bit for bit against
+    one launch per level."""
+    rs = np.random.RandomState(13)
+    for (nr, nc) in ((2048, 2048), (4096, 512), (1040, 4096), (2312, 2056), (8192, 256)):
+        x = rs.uniform(-100, 100, (nr, nc)).astype(np.float32)
+        with knobs(casc=0, casc_min=0):
+            R = pdwt_amd.Wavelets(x, wname, 2)
+            R.forward()
+            ref_c = R.coeffs
+        for kn in (dict(), dict(casc_nv=4), dict(casc_wg=1), dict(casc_wg=4), dict(casc_wg=8), dict(casc_wg=8, casc_nv=2),
+                   dict(casc_waves=1024), dict(casc_waves=2048), dict(casc_wg=1, casc_waves=512)):
+            with knobs(casc_min=0, **kn):
+                W = pdwt_amd.Wavelets(x, wname, 2)
+                W.forward()
+                for k, (a, b) in enumerate(zip(W.coeffs, ref_c)):
+                    assert np.array_equal(a, b), (wname, nr, nc, kn, "band", k)
