@@ -100,6 +100,30 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     auto off1 = [&](int r1) { return (size_t)CASC_DIAG_LD(wrap1(P0 + r1, Nr1)) * Nc1; };
     const unsigned voff3 = (unsigned)c3w * 4u, voff2 = (unsigned)cx2w * 4u, voff1 = (unsigned)cx1w * 4u, voffo = (unsigned)(valid ? cx1 : 0) * 8u;
     const lanemask_t vmask = __ballot(valid);
+    // Scalar bookkeeping of the loop (cf. k_fwd2d_casc): every stream of rows is walked by a cursor -- a 32-bit byte offset inside its band
+    // (bands of 4 GiB and more never get here), folded into the lane offset by one v_add per row group, advanced by the band's row stride,
+    // frozen at the last row the wave needs, wrapped on the offset itself -- instead of wrap + 64-bit multiply + 64-bit add per band and row;
+    // the output rows are walked by a 64-bit pointer, and rows the wave does not own are stored with EXEC = 0 (no trash select).
+    constexpr int kFold = (PDWT_CASC_DIAG & 2) ? 32 : 0;  // (diagnostic builds: loads folded onto 32 rows)
+    const unsigned str3 = (unsigned)Nc3 * 4u, str2 = (unsigned)Nc2 * 4u, str1 = (unsigned)Nc1 * 4u;
+    const unsigned end3 = (unsigned)(kFold ? min(kFold, Nr3) : Nr3) * str3, end2 = (unsigned)(kFold ? min(kFold, Nr2) : Nr2) * str2,
+                   end1 = (unsigned)(kFold ? min(kFold, Nr1) : Nr1) * str1;
+    int c3 = min(T0 + H2, last3), c2 = min(H2, last2), c1 = min(2, last1);  // stream rows of the next loads
+    unsigned o3 = (unsigned)CASC_DIAG_LD(wrapi(P3_0 - C + c3, Nr3)) * str3, o2 = (unsigned)CASC_DIAG_LD(wrap1(Q0 + c2, Nr2)) * str2,
+             o1 = (unsigned)CASC_DIAG_LD(wrap1(P0 + c1, Nr1)) * str1;
+    auto advance = [&](int& c, unsigned& o, int lastc, unsigned str, unsigned end) {
+        int cq = c;
+        asm("" : "+s"(cq));  // (a scalar compare of its own, cf. k_fwd2d_casc)
+        if (cq < lastc) {
+            c++;
+            o += str;
+            if (o == end) o = 0;
+        }
+    };
+    int orow = CASC_DIAG_ST(wrap1(O0, Nr));  // output row of the next OWN emit (own windows are consecutive: g = 0, 1, 2, ...)
+    float* op = out + (size_t)orow * Nc;
+    const int oend = (PDWT_CASC_DIAG & 1) ? min(32, Nr) : Nr;
+    (void)trash;
 
     // LDS: the hand-off regions
     constexpr int REG = casc_inv3_region_bytes<HLEN>();
@@ -249,7 +273,6 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
         for (int r = 0; r < H2 - 1; r++) *lds_l2(lds_wr, r) = v4f{r2av[r].x, r2av[r].y, r2hd[r].x, r2hd[r].y};
     }
 
-    float* const tr = trash + (size_t)(blockIdx.x & 7) * Nc;  // a trash ROW (the dispatcher checks the area holds 8 of them)
 
     // one output row of level l from the ring window starting at slot S0 with tap parity OFF: the lane holds the coefficient columns
     // (c0, c0+1) and owns the outputs 2 c0 .. 2 c0 + 3 = second output of window p = c0 (computed by the lane to the LEFT as the
@@ -293,7 +316,15 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
             const v2f pb = nat_pair(t1w + 1, t2w + 1);  // outputs 2 c0 + 3, 2 c0 + 4 (the second belongs to the lane to the right)
             o4 = v4f{dpp_shr1(pb.y), pa.x, pa.y, pb.x};
         }
-        asm_store_sm(own ? out + (size_t)CASC_DIAG_ST(wrap1(O0 + g, Nr)) * Nc : tr, voffo, o4, vmask);
+        (void)g;
+        asm_store_sm(op, voffo, o4, own ? vmask : 0ull);
+        if (own) {
+            op += Nc;
+            if (++orow == oend) {
+                orow = 0;
+                op = out;
+            }
+        }
     };
 
     auto step = [&](auto Pp, int sb) {
@@ -316,11 +347,12 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
                 r3hd[H2 - 1] = v2f{asm_copy(q3[1]), asm_copy(q3[3])};
                 {
                     // the row the even step after this one inserts: stream row T0 + s/2 + H2 (clamped to the last one needed)
-                    const size_t o = off3(min(T0 + (s >> 1) + H2, last3));
-                    asm_load_s(q3[0], b3.A3 + o, voff3);
-                    asm_load_s(q3[1], b3.H3 + o, voff3);
-                    asm_load_s(q3[2], b3.V3 + o, voff3);
-                    asm_load_s(q3[3], b3.D3 + o, voff3);
+                    const unsigned vo = voff3 + o3;
+                    asm_load_s(q3[0], b3.A3, vo);
+                    asm_load_s(q3[1], b3.H3, vo);
+                    asm_load_s(q3[2], b3.V3, vo);
+                    asm_load_s(q3[3], b3.D3, vo);
+                    advance(c3, o3, last3, str3, end3);
                 }
             }
             // the A part of stream row s2: first (even step: tap parity 1) or second output of the current level-(l+2) window
@@ -341,11 +373,12 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
             r2av[sl] = v2f{e.x, e.y};
             r2hd[sl] = v2f{e.z, e.w};
             {
-                const size_t o = off2(min(s2 + 1, last2));  // the row needed one step ahead (clamped to the last one the wave loads)
-                if constexpr (!L3) asm_load_s(q2[0], b.A2 + o, voff2);
-                asm_load_s(q2[1], b.H2 + o, voff2);
-                asm_load_s(q2[2], b.V2 + o, voff2);
-                asm_load_s(q2[3], b.D2 + o, voff2);
+                const unsigned vo = voff2 + o2;  // stream row s2 + 1, needed one step ahead (frozen at the last one the wave loads)
+                if constexpr (!L3) asm_load_s(q2[0], b.A2, vo);
+                asm_load_s(q2[1], b.H2, vo);
+                asm_load_s(q2[2], b.V2, vo);
+                asm_load_s(q2[3], b.D2, vo);
+                advance(c2, o2, last2, str2, end2);
             }
         }
         static_for<2>([&](auto I) {
@@ -362,10 +395,11 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
                 rv[sl] = asm_copy(q1[idx][1]);
                 rd[sl] = asm_copy(q1[idx][2]);
                 {
-                    const size_t o = off1(min(r1 + 2, last1));
-                    asm_load_s(q1[idx][0], b.H1 + o, voff1);
-                    asm_load_s(q1[idx][1], b.V1 + o, voff1);
-                    asm_load_s(q1[idx][2], b.D1 + o, voff1);
+                    const unsigned vo = voff1 + o1;  // stream row r1 + 2 (frozen at the last one)
+                    asm_load_s(q1[idx][0], b.H1, vo);
+                    asm_load_s(q1[idx][1], b.V1, vo);
+                    asm_load_s(q1[idx][2], b.D1, vo);
+                    advance(c1, o1, last1, str1, end1);
                 }
                 if constexpr (q < H2 - 1) {
                     // first steps: the wave above needs this wave's first H2-1 level-l ring rows
@@ -509,6 +543,7 @@ int inv2d_casc3_f32(const float* A2, const float* H2, const float* V2, const flo
 {
     const bool l3 = A3 != nullptr;
     if ((nr & 7) || (nc & 7) || nc < 256 || nr < 32 * hlen) return 1;
+    if ((long long)nr * nc >= (1LL << 32)) return 1;  // 32-bit row offsets inside a level-l band: larger images take one launch per level
     if (!al16(out) || !al16(H1) || !al16(V1) || !al16(D1) || !al16(H2) || !al16(V2) || !al16(D2) || !al16(trash)) return 1;
     if (!l3 && !al16(A2)) return 1;
     const CascInvBands b = {A2, H2, V2, D2, H1, V1, D1};

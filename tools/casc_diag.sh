@@ -1,6 +1,6 @@
 #!/bin/bash
 # Diagnostic libraries for the streamed inverse cascade (C2; the forward cascade lost its folding hooks when its row addressing went
-# incremental -- commit df608f3 still has them): pdwt_amd/lib_cdiag<k> = the product library with dwt_casc_inv3.hip
+# incremental -- commit df608f3 still has them; the inverse folds through its row cursors): pdwt_amd/lib_cdiag<k> = the product library with dwt_casc_inv3.hip
 # compiled with -DPDWT_CASC_DIAG=<k> (1: stored rows folded onto 32 rows, 2: loaded rows folded, 3: both -> results are WRONG, the timings
 # say what the kernels cost without their memory traffic).  PDWT_LIBDIR=$PWD/pdwt_amd/lib_cdiag<k> python bench.py --config c2 ...
 cd "$(dirname "$0")/.."
