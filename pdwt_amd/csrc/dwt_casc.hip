@@ -215,22 +215,23 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
     // wave's last row -- twice that row, a cached re-read); the image wrap (at most once per wave) takes the slow branch
     int lr = HLEN - 2 + NV;                                   // chunk-local row of the next pair (even)
     int lgr = wrap1(yb + min(lr, rlast), Nr);                 // its image row
-    const float* lp = in + (size_t)lgr * Nc;
-    const float* lplast = lp;                                 // the last row fetched (what a frozen pair re-reads)
-    const size_t strideF = (size_t)Nc;
-    auto next_rows = [&](const float*& p0, const float*& p1) {
+    const size_t strideB = (size_t)Nc * 4;                    // (byte pointers: no shift per advance)
+    const char* const inB = reinterpret_cast<const char*>(in);
+    const char* lp = inB + (size_t)lgr * strideB;
+    const char* lplast = lp;                                  // the last row fetched (what a frozen pair re-reads)
+    auto next_rows = [&](const char*& p0, const char*& p1) {
         int lrq = lr;
         asm("" : "+s"(lrq));  // (a compare of its own: hipcc otherwise keeps the predicate as a lane mask, 3 scalar instructions per use)
         if (lrq < rlast) {
             p0 = lp;
             if (lgr + 2 < Nr) {
-                p1 = lp + strideF;
-                lp = p1 + strideF;
+                p1 = lp + strideB;
+                lp = p1 + strideB;
                 lgr += 2;
             } else {
-                p1 = (lgr + 1 == Nr) ? in : lp + strideF;
-                lgr = (lgr + 2 >= Nr) ? lgr + 2 - Nr : lgr + 2;
-                lp = in + (size_t)lgr * Nc;
+                p1 = (lgr + 1 == Nr) ? inB : lp + strideB;
+                lgr = lgr + 2 - Nr;
+                lp = inB + (size_t)lgr * strideB;
             }
             lplast = p1;
         } else {
@@ -276,10 +277,10 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                 // rows 2n + HLEN-2 + NV and the next one, DIST A1 rows ahead (frozen at the wave's last row: the prefetch past the end
                 // re-reads a cached line instead of fetching new ones)
                 {
-                    const float *p0, *p1;
+                    const char *p0, *p1;
                     next_rows(p0, p1);
-                    asm_load_s(v[r0], p0, xoff);
-                    asm_load_s(v[r1], p1, xoff);
+                    asm_load_s(v[r0], reinterpret_cast<const float*>(p0), xoff);
+                    asm_load_s(v[r1], reinterpret_cast<const float*>(p1), xoff);
                 }
                 // level-1 column pass
                 v2f ah[2], vd[2];
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                     ah2 = pk_fma(splat(ring2[s].x), t, ah2);
                     vd2 = pk_fma(splat(ring2[s].y), t, vd2);
                 });
-                const bool own = (n >= HLEN - 1) && (n < HLEN - 1 + 2 * rows2);  // level-2 row (n - (HLEN-1)) / 2 of the wave's rows2
+                const bool own = (unsigned)(n - (HLEN - 1)) < (unsigned)(2 * rows2);  // level-2 row (n - (HLEN-1)) / 2 of the wave's rows2
                 asm_store4_sm(b.A2, b.H2, b.V2, b.D2, off2 + s2off, ah2.x, ah2.y, vd2.x, vd2.y, own ? vmask : 0ull);
                 s2off += own ? (unsigned)Nc4 * 4u : 0u;
             }
