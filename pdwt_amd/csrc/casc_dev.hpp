@@ -28,6 +28,7 @@ struct CascMap {
     int cpx;     // W == 1: chunk rows per XCD (all 8 XCDs get the same number); W > 1: workgroups per XCD
     int strips;  // strips per chunk row
     int gy;      // W > 1: workgroup-chunk rows (gy * strips workgroups in all)
+    int flags;   // bit 0: waves whose row counts have a straight-line instantiation run it (knob casc_spec)
 };
 struct CascBands {
     float *H1, *V1, *D1, *A2, *H2, *V2, *D2;

@@ -126,6 +126,7 @@ enum KnobId {
     KN_CASC_WG,            // forward cascade: waves stacked per workgroup with LDS ring hand-off (0 = auto, 1 = independent waves)
     KN_CASC_IWG,           // inverse cascade: the same (0 = auto, 1 = independent waves)
     KN_CASC_L3,            // third level folded into the inverse cascade launch: 1 = streamed (dwt_casc_inv3.hip) where it applies, 2 = prologue form only, 0 = never
+    KN_CASC_SPEC,          // cascade kernels: straight-line wave programs for the common per-wave row counts (bit 0 forward, bit 1 inverse)
     KN_STREAM,             // 0: LDS-tiled fused level kernels instead of the streaming ones
     KN_STREAM_R,           // streaming level kernels: rows per wave (0 = auto)
     KN_STREAM_WAVES,       // streaming level kernels: target waves per launch

@@ -327,6 +327,137 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                 s2off += own ? (unsigned)Nc4 * 4u : 0u;
             }
     };
+    // ---- straight-line wave programs (W = 16, one A1 row of prefetch) -------------------------------------------------------------
+    // A wave of this form lives for 16-odd A1 rows: it is all prologue and epilogue, and in the loop below every A1 row pays ~45
+    // scalar instructions for predicates and cursors (where does the row come from, is it owned, has the image wrapped, is the wave
+    // past its last row) on a kernel that is bound by instruction issue (+40 scalar instructions per A1 row = +3.5 us).
+    // For the row counts the default geometry produces (non-last waves with R2 level-2 rows, the last wave with its reduced count)
+    // the whole wave program is instantiated with the A1 row index as a compile-time constant: every predicate folds away, stores
+    // of rows the wave does not own and the arithmetic that only feeds them are not emitted, the vmcnt waits are constants of the
+    // position, and the only wave-dependent addressing left is a 64-bit row pointer (+ 2 rows per A1 row) and two running store
+    // offsets.  The two places where a wave's rows wrap around the image are compile-time positions as well: the first wave of
+    // the top workgroups (local input row 3C, level-1 row C) and the last wave of the bottom workgroups (local row 4*R2 + 3C).
+    // Same arithmetic, same order: bit-identical to the loop (tests: test_forward_cascade_row_cursors).
+    bool spec_done = false;
+    if constexpr (W == 16 && NV == 2) {
+        const unsigned xoff_odd = xoff + (unsigned)strideB;  // second row of a pair: same scalar base, the row stride in the lane offset
+        auto spec = [&](auto R2c, auto LASTc) {
+            constexpr int R2 = decltype(R2c)::value;
+            constexpr bool LV = decltype(LASTc)::value;
+            constexpr int sNA = 2 * R2, sNA1 = sNA + HLEN - 2, sNL1 = sNA - HLEN / 2 + 1;
+            constexpr int WR = LV ? 4 * R2 + 3 * C : 3 * C;  // local input row at which the image wraps, for the waves that wrap at all
+            const bool wraps = LV ? (j0 + R2 == Nr4) : (j0 == 0);
+            const size_t wrapB = wraps ? (size_t)Nr * strideB : (size_t)0;
+            const unsigned s1wrap = (!LV && j0 == 0) ? s1end : 0u;
+            const char* sp = lp;  // local row HLEN (already wrapped: the prologue's row arithmetic)
+            static_for<sNA1>([&](auto Nn) {
+                constexpr int n = decltype(Nn)::value;
+                constexpr int a = n % HLEN;
+                constexpr bool from_mem = LV ? true : (n < sNL1);
+                constexpr bool computed = LV ? true : (n < sNA);
+                constexpr bool store1 = n < sNA;
+                constexpr int s0 = (2 * n + HLEN - 2) % HLEN, s1 = (2 * n + HLEN - 1) % HLEN;
+                if constexpr (computed) {
+                    if constexpr (from_mem) {
+                        if constexpr (n > 0) {
+                            // VMEM instructions issued since this row's loads (at A1 row n-1): that row's stores
+                            constexpr int m = n - 1;
+                            constexpr int cnt = ((m < sNA) ? 3 : 0) + (((m & 1) && m >= HLEN - 1) ? 4 : 0);
+                            asm_wait2<cnt>(v[0], v[1]);
+                        }
+                        row_pass1(v[0], ring[s0]);
+                        row_pass1(v[1], ring[s1]);
+                        constexpr bool more = LV ? (n + 1 < sNA1) : (n + 1 < sNL1);
+                        if constexpr (more) {
+                            constexpr int r0 = 2 * (n + 1) + HLEN - 2;  // sp points at local row r0
+                            // (the row registers start a new life here: without this the tied loads make hipcc carry the dead old values
+                            // into whatever registers it picked for the new ones, two v_mov_b64 per load)
+                            asm volatile("" : "=v"(v[0]));
+                            asm volatile("" : "=v"(v[1]));
+                            asm_load_s(v[0], reinterpret_cast<const float*>(sp), xoff);
+                            if constexpr (r0 + 1 == WR) {
+                                asm_load_s(v[1], reinterpret_cast<const float*>(sp + strideB - wrapB), xoff);
+                            } else {
+                                asm_load_s(v[1], reinterpret_cast<const float*>(sp), xoff_odd);
+                            }
+                            sp += 2 * strideB;
+                            if constexpr (r0 + 1 == WR || r0 + 2 == WR) sp -= wrapB;
+                        }
+                    } else {
+                        constexpr int i0 = 2 * (n - sNL1);
+                        const v4f q0 = *lds_ring(lds_rd, i0), q1 = *lds_ring(lds_rd, i0 + 1);
+                        ring[s0][0] = v2f{q0.x, q0.y};
+                        ring[s0][1] = v2f{q0.z, q0.w};
+                        ring[s1][0] = v2f{q1.x, q1.y};
+                        ring[s1][1] = v2f{q1.z, q1.w};
+                    }
+                    v2f ah[2], vd[2];
+#pragma unroll
+                    for (int p = 0; p < 2; p++) ah[p] = vd[p] = v2f{0.f, 0.f};
+                    static_for<HLEN>([&](auto J) {
+                        constexpr int j = decltype(J)::value;
+                        constexpr int s = (2 * n + j) % HLEN;
+                        const v2f t = f.t[HLEN - 1 - j];
+#pragma unroll
+                        for (int p = 0; p < 2; p++) {
+                            ah[p] = pk_fma_vbcast<0, j == 0>(ring[s][p], t, ah[p]);
+                            if constexpr (store1) vd[p] = pk_fma_vbcast<1, j == 0>(ring[s][p], t, vd[p]);
+                        }
+                    });
+                    if constexpr (store1) {
+                        asm_store3_sm(b.H1, b.V1, b.D1, off1 + s1off, v2f{ah[0].y, ah[1].y}, v2f{vd[0].x, vd[1].x}, v2f{vd[0].y, vd[1].y}, vmask);
+                        s1off += (unsigned)Nc2 * 4u;
+                        if constexpr (n == C - 1) s1off -= s1wrap;
+                    }
+                    row_pass2(ah[0].x, ah[1].x, ring2[a]);
+                    if constexpr (n < HLEN - 2) {
+                        if (kw > 0) *lds_ring2(lds_wr, n) = ring2[a];
+                    }
+                } else {
+                    ring2[a] = *lds_ring2(lds_rd, n - sNA);
+                }
+                if constexpr ((n & 1) && n >= HLEN - 1) {
+                    v2f ah2 = {0.f, 0.f}, vd2 = {0.f, 0.f};
+                    static_for<HLEN>([&](auto J) {
+                        constexpr int j = decltype(J)::value;
+                        constexpr int s = (a + 1 + j) % HLEN;
+                        const v2f t = f.t[HLEN - 1 - j];
+                        ah2 = pk_fma_vbcast<0, j == 0>(ring2[s], t, ah2);
+                        vd2 = pk_fma_vbcast<1, j == 0>(ring2[s], t, vd2);
+                    });
+                    asm_store4_sm(b.A2, b.H2, b.V2, b.D2, off2 + s2off, ah2.x, ah2.y, vd2.x, vd2.y, vmask);
+                    s2off += (unsigned)Nc4 * 4u;
+                }
+                // the two hand-off barriers of the first super-body (see the loop below)
+                if constexpr (n == HLEN / 2 - 1 || n == HLEN - 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef PDWT_CASC_TRACE
+                if constexpr (n == HLEN / 2 - 1) CASC_TRACE(3);
+                if constexpr (n == HLEN - 1) CASC_TRACE(4);
+#endif
+            });
+        };
+        // one if / else chain with the loop as its last arm: nothing of the loop's state is live across a wave program
+        int variant = 0;
+        if (cm.flags & 1) {
+            if (!last) {
+                if (2 * 4 >= HLEN && rows2 == 4) variant = 1;
+                if (2 * 5 >= HLEN && rows2 == 5) variant = 2;
+            } else if (rows2 == 1) {
+                variant = 3;
+            }
+        }
+        if (variant == 1) {
+            spec(std::integral_constant<int, 4>{}, std::false_type{});
+            spec_done = true;
+        } else if (variant == 2) {
+            spec(std::integral_constant<int, 5>{}, std::false_type{});
+            spec_done = true;
+        } else if (variant == 3) {
+            spec(std::integral_constant<int, 1>{}, std::true_type{});
+            spec_done = true;
+        }
+    }
+    if (!spec_done)
     for (int sb = 0;; sb++) {
         static_for<HLEN / 2>([&](auto U) { a1_row(std::integral_constant<int, decltype(U)::value>{}, sb); });
         // Hand-off order (W > 1): the ring rows are written in the prologue and first read at A1 row NL1 >= HLEN/2, the ring2 rows
@@ -678,7 +809,7 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
         while (gy > 1 && (nr4 / gy) / W < HLEN / 2) gy--;  // every wave needs >= HLEN/2 level-2 rows (see the kernel)
         if (gy >= 1 && (nr4 / gy) / W >= HLEN / 2) {
             const int nwg = gy * strips;
-            const CascMap cm = {idiv_up(nwg, 8), strips, gy};
+            const CascMap cm = {idiv_up(nwg, 8), strips, gy, knob(KN_CASC_SPEC) & 1};
             const dim3 grid((unsigned)(8 * cm.cpx));
             const size_t lds = (size_t)(W - 1) * REG;  // hand-off regions
             // (HLEN row registers in flight instead of HLEN/2 measured slower in this form too: 24.8 vs 24.6 us at W = 8)
@@ -720,7 +851,11 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
     return PDWT_OK;
 }
 
+#ifdef PDWT_CASC_ONLY8  // (quick ISA inspection builds)
+#define PDWT_CASC_FWD_HLENS(X) X(8)
+#else
 #define PDWT_CASC_FWD_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
+#endif
 
 int fwd2d_casc_f32(const float* in, float* H1, float* V1, float* D1, float* A2, float* H2, float* V2, float* D2, float* trash, int nr,
                    int nc, int hlen, const Taps2<float>& f)
@@ -775,7 +910,11 @@ static int launch_inv_casc(const CascInvBands& b, float* out, float* trash, int 
 }
 
 // (hlen >= 12: two single-level launches are faster in this direction -- 37.9 vs 41.3 us db6, 52.4 vs 59.6 us db8 at 4096^2)
+#ifdef PDWT_CASC_ONLY8
+#define PDWT_CASC_INV_HLENS(X) X(8)
+#else
 #define PDWT_CASC_INV_HLENS(X) X(4) X(6) X(8) X(10)
+#endif
 
 int inv2d_casc_f32(const float* A2, const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1,
                    float* out, float* trash, int nr, int nc, int hlen, const Taps2<float>& f)

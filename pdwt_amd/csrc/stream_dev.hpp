@@ -72,6 +72,25 @@ __device__ __forceinline__ v2f pk_fma_sbcast(v2f v, v2f spair, v2f acc)
     }
 }
 
+// acc += splat(one half of a VGPR pair) * (an SGPR pair as it is): the forward column passes, (A, H) += lo * (L[k], H[k]) and
+// (V, D) += hi * (L[k], H[k]) with (lo, hi) a ring entry.  Written out because in straight-line code (the specialised wave programs of
+// dwt_casc.hip) hipcc CSEs the splat of a ring value over the eight column passes that use it and keeps it as a materialised register
+// PAIR (two v_mov per value, twice the ring's registers -> spills) instead of using the broadcast of the instruction.
+template <int HALF, bool FIRST>
+__device__ __forceinline__ v2f pk_fma_vbcast(v2f v, v2f spair, v2f acc)
+{
+    if constexpr (FIRST) {
+        v2f r;
+        if constexpr (HALF == 0) asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(v), "s"(spair));
+        else asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(v), "s"(spair));
+        return r;
+    } else {
+        if constexpr (HALF == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(v), "s"(spair));
+        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc) : "v"(v), "s"(spair));
+        return acc;
+    }
+}
+
 // forward taps as (L[k], H[k]) pairs, by value in the kernarg segment (-> SGPR pairs)
 struct TapsLH {
     v2f t[PDWT_MAX_FILTER_WIDTH];
