@@ -47,6 +47,24 @@ constexpr int casc_fwd_after(int p)
 template <int HLEN>
 constexpr int casc_fwd_region_bytes() { return (HLEN - 2) * 64 * (16 + 8); }
 
+// Bookkeeping of a straight-line wave program (see the kernel): R2 level-2 rows, last wave of its workgroup or not, DIST A1 rows
+// of prefetch.  Everything here is a function of the A1 row index alone.
+template <int HLEN, int R2, bool LV, int DIST>
+struct CascSpec {
+    static constexpr int NA = 2 * R2, NA1 = NA + HLEN - 2, NL1 = NA - HLEN / 2 + 1;
+    static constexpr int LIM = LV ? NA1 : NL1;  // A1 rows below LIM take their two new input rows from memory
+    static constexpr int stores_at(int q) { return ((q < NA) ? 3 : 0) + (((q & 1) && q >= HLEN - 1) ? 4 : 0); }
+    static constexpr int loads_at(int q) { return (q < LIM && q + DIST < LIM) ? 2 : 0; }
+    // VMEM instructions between the loads issued at A1 row n - DIST and their use at A1 row n
+    static constexpr int wait_cnt(int n)
+    {
+        const int m = n - DIST;
+        int c = stores_at(m);
+        for (int k = 1; k < DIST; k++) c += loads_at(m + k) + stores_at(m + k);
+        return c;
+    }
+};
+
 // NV = row registers = input rows (KiB) in flight per wave = prefetch distance (HLEN/2, HLEN or 2*HLEN)
 // W  = waves of a workgroup stacked vertically in ONE strip (1 = independent waves, four strips per workgroup).
 //
@@ -59,7 +77,8 @@ constexpr int casc_fwd_region_bytes() { return (HLEN - 2) * 64 * (16 + 8); }
 //   W  > 1: the wave below has those row-pass results in its rings anyway (its ring warm-up).  It drops them in LDS during
 //           its first super-body; one s_barrier later every wave can pick up its bottom halo at the END of its chunk: no
 //           extra loads, no recomputation, and the waves of a workgroup are balanced by giving the last one fewer rows.
-template <int HLEN, int NV, int W>
+// SPEC = true: the kernel consists of the straight-line wave programs only (the host launches it when every wave of the geometry has one)
+template <int HLEN, int NV, int W, bool SPEC = false>
 __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const float* __restrict__ in, CascBands b, int Nr, int Nc, int VL,
                                                                        float* __restrict__ trash, CascMap cm, TapsLH f)
 {
@@ -338,13 +357,23 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
     // offsets.  The two places where a wave's rows wrap around the image are compile-time positions as well: the first wave of
     // the top workgroups (local input row 3C, level-1 row C) and the last wave of the bottom workgroups (local row 4*R2 + 3C).
     // Same arithmetic, same order: bit-identical to the loop (tests: test_forward_cascade_row_cursors).
-    bool spec_done = false;
-    if constexpr (W == 16 && NV == 2) {
+    // (a wave program has consumed every row it loaded: only stores are in flight at its end, and nothing has to wait for them)
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        CASC_TRACE(5);  // loop left
+#ifdef PDWT_CASC_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        CASC_TRACE(6);  // everything this wave issued has retired
+        CASC_TRACE_STORE(trash, blockIdx.x * W + kw, ((unsigned long long)NA1 << 32) | (unsigned)rows2);
+    };
+    if constexpr (SPEC) {
+        static_assert(W == 16 && (NV == 2 || NV == 4), "wave programs exist for the 16-wave workgroups");
         const unsigned xoff_odd = xoff + (unsigned)strideB;  // second row of a pair: same scalar base, the row stride in the lane offset
-        auto spec = [&](auto R2c, auto LASTc) {
+        auto spec = [&](auto R2c, auto LASTc) __attribute__((always_inline)) {
             constexpr int R2 = decltype(R2c)::value;
             constexpr bool LV = decltype(LASTc)::value;
-            constexpr int sNA = 2 * R2, sNA1 = sNA + HLEN - 2, sNL1 = sNA - HLEN / 2 + 1;
+            using S = CascSpec<HLEN, R2, LV, DIST>;
+            constexpr int sNA = S::NA, sNA1 = S::NA1, sNL1 = S::NL1;
             constexpr int WR = LV ? 4 * R2 + 3 * C : 3 * C;  // local input row at which the image wraps, for the waves that wrap at all
             const bool wraps = LV ? (j0 + R2 == Nr4) : (j0 == 0);
             const size_t wrapB = wraps ? (size_t)Nr * strideB : (size_t)0;
@@ -359,26 +388,22 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                 constexpr int s0 = (2 * n + HLEN - 2) % HLEN, s1 = (2 * n + HLEN - 1) % HLEN;
                 if constexpr (computed) {
                     if constexpr (from_mem) {
-                        if constexpr (n > 0) {
-                            // VMEM instructions issued since this row's loads (at A1 row n-1): that row's stores
-                            constexpr int m = n - 1;
-                            constexpr int cnt = ((m < sNA) ? 3 : 0) + (((m & 1) && m >= HLEN - 1) ? 4 : 0);
-                            asm_wait2<cnt>(v[0], v[1]);
-                        }
-                        row_pass1(v[0], ring[s0]);
-                        row_pass1(v[1], ring[s1]);
-                        constexpr bool more = LV ? (n + 1 < sNA1) : (n + 1 < sNL1);
-                        if constexpr (more) {
-                            constexpr int r0 = 2 * (n + 1) + HLEN - 2;  // sp points at local row r0
+                        constexpr int q0 = (2 * n) % NV, q1 = q0 + 1;
+                        // (the first DIST A1 rows use the rows the prologue loaded and drained)
+                        if constexpr (n >= DIST) asm_wait2<S::wait_cnt(n)>(v[q0], v[q1]);
+                        row_pass1(v[q0], ring[s0]);
+                        row_pass1(v[q1], ring[s1]);
+                        if constexpr (n + DIST < S::LIM) {
+                            constexpr int r0 = 2 * (n + DIST) + HLEN - 2;  // sp points at local row r0
                             // (the row registers start a new life here: without this the tied loads make hipcc carry the dead old values
                             // into whatever registers it picked for the new ones, two v_mov_b64 per load)
-                            asm volatile("" : "=v"(v[0]));
-                            asm volatile("" : "=v"(v[1]));
-                            asm_load_s(v[0], reinterpret_cast<const float*>(sp), xoff);
+                            asm volatile("" : "=v"(v[q0]));
+                            asm volatile("" : "=v"(v[q1]));
+                            asm_load_s(v[q0], reinterpret_cast<const float*>(sp), xoff);
                             if constexpr (r0 + 1 == WR) {
-                                asm_load_s(v[1], reinterpret_cast<const float*>(sp + strideB - wrapB), xoff);
+                                asm_load_s(v[q1], reinterpret_cast<const float*>(sp + strideB - wrapB), xoff);
                             } else {
-                                asm_load_s(v[1], reinterpret_cast<const float*>(sp), xoff_odd);
+                                asm_load_s(v[q1], reinterpret_cast<const float*>(sp), xoff_odd);
                             }
                             sp += 2 * strideB;
                             if constexpr (r0 + 1 == WR || r0 + 2 == WR) sp -= wrapB;
@@ -430,34 +455,30 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                 }
                 // the two hand-off barriers of the first super-body (see the loop below)
                 if constexpr (n == HLEN / 2 - 1 || n == HLEN - 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
 #ifdef PDWT_CASC_TRACE
                 if constexpr (n == HLEN / 2 - 1) CASC_TRACE(3);
                 if constexpr (n == HLEN - 1) CASC_TRACE(4);
 #endif
             });
         };
-        // one if / else chain with the loop as its last arm: nothing of the loop's state is live across a wave program
-        int variant = 0;
-        if (cm.flags & 1) {
-            if (!last) {
-                if (2 * 4 >= HLEN && rows2 == 4) variant = 1;
-                if (2 * 5 >= HLEN && rows2 == 5) variant = 2;
-            } else if (rows2 == 1) {
-                variant = 3;
-            }
-        }
+        // The wave programs live in a kernel of their own: next to the loop in ONE kernel, hipcc's control-flow structuriser chains the arms
+        // (arm 1 -> flag -> arm 2 ... -> loop) and the register allocator keeps every arm's entry state alive, in scratch, around the others.
+        // Every arm but the last ends the program itself (s_endpgm instead of a return to a common exit) for the same reason.
+        const int variant = __builtin_amdgcn_readfirstlane(last ? 3 : (rows2 == 5 ? 2 : 1));
         if (variant == 1) {
             spec(std::integral_constant<int, 4>{}, std::false_type{});
-            spec_done = true;
-        } else if (variant == 2) {
-            spec(std::integral_constant<int, 5>{}, std::false_type{});
-            spec_done = true;
-        } else if (variant == 3) {
-            spec(std::integral_constant<int, 1>{}, std::true_type{});
-            spec_done = true;
+            epilogue();
+            __builtin_amdgcn_endpgm();
         }
-    }
-    if (!spec_done)
+        if (variant == 2) {
+            spec(std::integral_constant<int, 5>{}, std::false_type{});
+            epilogue();
+            __builtin_amdgcn_endpgm();
+        }
+        spec(std::integral_constant<int, 1>{}, std::true_type{});
+        epilogue();
+    } else {
     for (int sb = 0;; sb++) {
         static_for<HLEN / 2>([&](auto U) { a1_row(std::integral_constant<int, decltype(U)::value>{}, sb); });
         // Hand-off order (W > 1): the ring rows are written in the prologue and first read at A1 row NL1 >= HLEN/2, the ring2 rows
@@ -479,10 +500,9 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
 #endif
         if (sb * HLEN + HLEN >= NA1) break;
     }
-    CASC_TRACE(5);  // loop left
     static_for<NV>([&](auto K) { asm_drain1(v[decltype(K)::value]); });
-    CASC_TRACE(6);  // everything this wave issued has retired
-    CASC_TRACE_STORE(trash, blockIdx.x * W + kw, ((unsigned long long)NA1 << 32) | (unsigned)rows2);
+    epilogue();
+    }
 }
 
 // =================================================================================================
@@ -809,7 +829,7 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
         while (gy > 1 && (nr4 / gy) / W < HLEN / 2) gy--;  // every wave needs >= HLEN/2 level-2 rows (see the kernel)
         if (gy >= 1 && (nr4 / gy) / W >= HLEN / 2) {
             const int nwg = gy * strips;
-            const CascMap cm = {idiv_up(nwg, 8), strips, gy, knob(KN_CASC_SPEC) & 1};
+            const CascMap cm = {idiv_up(nwg, 8), strips, gy, 0};
             const dim3 grid((unsigned)(8 * cm.cpx));
             const size_t lds = (size_t)(W - 1) * REG;  // hand-off regions
             // (HLEN row registers in flight instead of HLEN/2 measured slower in this form too: 24.8 vs 24.6 us at W = 8)
@@ -819,10 +839,20 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
             // (4032 waves: 33 instead of 41 MB of read-only start): C2 forward 23.5-23.8 -> 23.1-23.2 us (casc_nv = hlen/2: the round-2 depth)
             const bool nv2 = W == 16 && (knob(KN_CASC_NV) == 0 || knob(KN_CASC_NV) == 2);
             if (nv2) k = k_fwd2d_casc<HLEN, 2, 16>;
+            // the straight-line wave programs (kernel form SPEC) exist for waves of 4 or 5 level-2 rows whose workgroup's last wave has 1:
+            // the kernel's split, replayed on the two chunk sizes that occur (C2: 73 or 74 level-2 rows over 16 waves)
+            bool spec = nv2 && (knob(KN_CASC_SPEC) & 1) && 2 * 4 >= HLEN;
+            for (int R : {nr4 / gy, idiv_up(nr4, gy)}) {
+                const int E = std::min((3 * (HLEN - 2) + 3) / 4, R / 16 - 1);
+                const int base = (R + E) / 16, rem = (R + E) % 16;
+                spec = spec && base == 4 && R - (15 * base + std::min(15, rem)) == 1;
+            }
+            if (spec) k = k_fwd2d_casc<HLEN, 2, 16, true>;
             if (lds > 64 * 1024) {  // opt-in once per (kernel, device), not per launch
                 int rc = (W == 4) ? lds_opt_in<k_fwd2d_casc<HLEN, NVD, 4>>()
                          : (W == 8) ? lds_opt_in<k_fwd2d_casc<HLEN, NVD, 8>>() : lds_opt_in<k_fwd2d_casc<HLEN, NVD, 16>>();
                 if (rc == PDWT_OK && nv2) rc = lds_opt_in<k_fwd2d_casc<HLEN, 2, 16>>();
+                if (rc == PDWT_OK && spec) rc = lds_opt_in<k_fwd2d_casc<HLEN, 2, 16, true>>();
                 if (rc != PDWT_OK) return rc;
             }
             PDWT_LAUNCH_KT(kt, k, grid, dim3(64 * W), lds, in, b, nr, nc, VL, trash, cm, f);

@@ -29,6 +29,10 @@
 
 namespace pdwt {
 
+// lambdas of the kernel: inlined wherever they are called (a call in front of s_endpgm counts as cold and would stay a CALL, with the wave's
+// whole state passed through scratch)
+#define PDWT_AI __attribute__((always_inline))
+
 struct CascInv3B {
     const float *A3, *H3, *V3, *D3;
 };
@@ -36,8 +40,36 @@ struct CascInv3B {
 template <int HLEN>
 constexpr int casc_inv3_region_bytes() { return (HLEN / 2 - 1) * 64 * (16 + 32); }
 
+// Bookkeeping of a straight-line wave program (see the kernel): NQ level-(l+1) rows, last wave of its workgroup or not.  Everything is a
+// function of the step index s: which parts of a step run, which loads it issues, how many VMEM instructions lie between a load
+// and its use.  Order of the VMEM instructions of a step (the loop's order): [level l+2: wait, 4 loads] [level l+1: wait, NL2 loads]
+// then for each of the two A_l rows: [wait, 3 loads] [up to 2 stores].
+template <int HLEN, int NQ, bool LV, bool L3>
+struct CascInvSpec {
+    using G = CascInvGeom<HLEN>;
+    static constexpr int H2 = G::H2, XS = H2 / 2, NSTEPS = NQ + XS, NP = 2 * NQ;
+    static constexpr int NL2 = L3 ? 3 : 4;
+    static constexpr bool l2act(int s) { return s >= 0 && s < NSTEPS && (LV || s < NQ); }        // the level-(l+1) part runs
+    static constexpr bool need2(int s) { return l2act(s) && (LV || s + H2 - 1 < NQ); }          // its new row is the wave's own (not from the hand-off)
+    static constexpr bool adv3(int s) { return L3 && !(s & 1) && (need2(s) || need2(s + 1)); }  // the level-(l+2) ring advances
+    static constexpr int n3(int s) { return (adv3(s) && adv3(s + 2)) ? 4 : 0;  }                // loads a step issues ...
+    static constexpr int n2(int s) { return (l2act(s) && need2(s + 1)) ? NL2 : 0; }
+    static constexpr int n1(int s) { return (l2act(s) && l2act(s + 1)) ? 3 : 0; }               // ... per A_l row
+    static constexpr bool own(int s, int idx) { return 2 * s + idx - (H2 - 1) >= 0 && 2 * s + idx - (H2 - 1) < NP; }
+    static constexpr int st(int s, int idx) { return own(s, idx) ? 2 : 0; }
+    static constexpr int total(int s) { return n3(s) + n2(s) + 2 * n1(s) + st(s, 0) + st(s, 1); }
+    // VMEM instructions issued after the load of a row register and before its use
+    static constexpr int wait3(int s) { return n2(s - 2) + 2 * n1(s - 2) + st(s - 2, 0) + st(s - 2, 1) + total(s - 1); }
+    static constexpr int wait2(int s) { return 2 * n1(s - 1) + st(s - 1, 0) + st(s - 1, 1) + n3(s); }
+    static constexpr int wait1(int s, int idx)
+    {
+        return idx == 0 ? st(s - 1, 0) + n1(s - 1) + st(s - 1, 1) + n3(s) + n2(s) : st(s - 1, 1) + n3(s) + n2(s) + n1(s) + st(s, 0);
+    }
+};
+
 // L3 = false: the same kernel on TWO levels (the A parts of the level-(l+1) rows are loaded like their H, V, D parts; no third ring)
-template <int HLEN, int W, bool L3>
+// SPEC = true: the kernel consists of the straight-line wave programs only (the host launches it when every wave of the geometry has one)
+template <int HLEN, int W, bool L3, bool SPEC = false>
 __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3B b3, float* __restrict__ out, int Nr, int Nc, int VL,
                                                          float* __restrict__ trash, CascMap cm, Taps2<float> f)
 {
@@ -95,9 +127,9 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     const int bp_addr = 4 * (((X0 + lane + 1) >> 1) - ((X0 + 1) >> 1) + C);
     const bool bp_odd = ((X0 + lane) & 1) != 0;
 
-    auto off3 = [&](int i) { return (size_t)CASC_DIAG_LD(wrapi(P3_0 - C + i, Nr3)) * Nc3; };
-    auto off2 = [&](int s2) { return (size_t)CASC_DIAG_LD(wrap1(Q0 + s2, Nr2)) * Nc2; };
-    auto off1 = [&](int r1) { return (size_t)CASC_DIAG_LD(wrap1(P0 + r1, Nr1)) * Nc1; };
+    auto off3 = [&](int i) PDWT_AI { return (size_t)CASC_DIAG_LD(wrapi(P3_0 - C + i, Nr3)) * Nc3; };
+    auto off2 = [&](int s2) PDWT_AI { return (size_t)CASC_DIAG_LD(wrap1(Q0 + s2, Nr2)) * Nc2; };
+    auto off1 = [&](int r1) PDWT_AI { return (size_t)CASC_DIAG_LD(wrap1(P0 + r1, Nr1)) * Nc1; };
     const unsigned voff3 = (unsigned)c3w * 4u, voff2 = (unsigned)cx2w * 4u, voff1 = (unsigned)cx1w * 4u, voffo = (unsigned)(valid ? cx1 : 0) * 8u;
     const lanemask_t vmask = __ballot(valid);
     // Scalar bookkeeping of the loop (cf. k_fwd2d_casc): every stream of rows is walked by a cursor -- a 32-bit byte offset inside its band
@@ -129,8 +161,8 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     constexpr int REG = casc_inv3_region_bytes<HLEN>();
     unsigned char* const lds_rd = lds_raw + (size_t)kw * REG;                    // written by wave kw+1
     unsigned char* const lds_wr = lds_raw + (size_t)(kw > 0 ? kw - 1 : 0) * REG;  // read by wave kw-1
-    auto lds_l2 = [&](unsigned char* reg, int r) { return reinterpret_cast<v4f*>(reg + ((size_t)r * 64 + lane) * 16); };
-    auto lds_l1 = [&](unsigned char* reg, int r, int h) {
+    auto lds_l2 = [&](unsigned char* reg, int r) PDWT_AI { return reinterpret_cast<v4f*>(reg + ((size_t)r * 64 + lane) * 16); };
+    auto lds_l1 = [&](unsigned char* reg, int r, int h) PDWT_AI {
         return reinterpret_cast<v4f*>(reg + (size_t)(H2 - 1) * 64 * 16 + (((size_t)r * 2 + h) * 64 + lane) * 16);
     };
 
@@ -154,7 +186,7 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
         fa2[i] = v2f{f.a[2 * i], f.a[2 * i + 1]};
         fb2[i] = v2f{f.b[2 * i], f.b[2 * i + 1]};
     }
-    auto nat_pair = [&](const float* t1w, const float* t2w) {  // t?w[j] = t[p-C+j]
+    auto nat_pair = [&](const float* t1w, const float* t2w) PDWT_AI {  // t?w[j] = t[p-C+j]
         v2f s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < H2; j++) {
@@ -193,7 +225,7 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
         return nat_pair(t1w, t2w);
     };
     // the lane's two columns (2c, 2c+1) of the level below: its own second output and the first output of the lane to the right
-    auto own_pair = [&](v2f p0) { return v2f{p0.y, dpp_shl1(p0.x)}; };
+    auto own_pair = [&](v2f p0) PDWT_AI { return v2f{p0.y, dpp_shl1(p0.x)}; };
     // one A_{l+1} value per lane of the main mapping from a level-(l+2) window: column X is the second output of level-(l+2)
     // column X/2 when X is even and the first output of column (X+1)/2 when it is odd
     auto a2_from = [&](const v2f (&av)[H2], const v2f (&hd)[H2], auto OFF) {
@@ -277,8 +309,10 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     // one output row of level l from the ring window starting at slot S0 with tap parity OFF: the lane holds the coefficient columns
     // (c0, c0+1) and owns the outputs 2 c0 .. 2 c0 + 3 = second output of window p = c0 (computed by the lane to the LEFT as the
     // second half of its last pair), the natural pair of p = c0+1, first output of p = c0+2
-    auto emit = [&](auto S0, auto OFF, bool own, int g) {
+    auto emit = [&](auto S0, auto OFF, auto own_, int g) PDWT_AI {
         constexpr int s0 = decltype(S0)::value, off = decltype(OFF)::value;
+        constexpr bool kOwnStatic = std::is_same<decltype(own_), std::true_type>::value;  // (wave programs: the row is known to be owned)
+        const bool own = own_;
         // rows of the ring warm-up / beyond the wave's windows: the store is still issued (to a trash row, the VMEM count must
         // not change) but the arithmetic is skipped -- a uniform branch
         v4f o4;
@@ -317,12 +351,17 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
             o4 = v4f{dpp_shr1(pb.y), pa.x, pa.y, pb.x};
         }
         (void)g;
-        asm_store_sm(op, voffo, o4, own ? vmask : 0ull);
-        if (own) {
-            op += Nc;
-            if (++orow == oend) {
-                orow = 0;
-                op = out;
+        if constexpr (kOwnStatic) {
+            asm_store_sm(op, voffo, o4, vmask);
+            op += Nc;  // (the one place where a wave program's rows wrap is handled by the caller)
+        } else {
+            asm_store_sm(op, voffo, o4, own ? vmask : 0ull);
+            if (own) {
+                op += Nc;
+                if (++orow == oend) {
+                    orow = 0;
+                    op = out;
+                }
             }
         }
     };
@@ -438,6 +477,173 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
         asm_drain1(q1[k][2]);
     });
     CASC_TRACE(2);  // first row registers landed
+
+    // ---- straight-line wave programs (cf. k_fwd2d_casc) ---------------------------------------------------------------------------
+    // A wave of the default geometry lives for 6 or 8 steps; in the loop below every step pays for predicates (does the level-(l+1) part
+    // run, is its row the wave's own or the neighbour's, which windows are owned), cursors that freeze at the wave's last row and wrap
+    // with the image, and for loads, waits and syntheses whose results a select then drops (the last H2-1 level-(l+1) rows of a wave
+    // that is not the last of its workgroup come from the hand-off, yet their A parts are synthesised and their V, H, D parts loaded).
+    // Here the step index is a compile-time constant: parts that do not run are not emitted, stores of rows the wave does not own do
+    // not exist, the vmcnt waits are constants of the position (CascInvSpec) and the only addressing left is three running 32-bit band
+    // offsets and the output row pointer.  The image wraps inside a wave program only for the last wave of the bottom workgroups, at
+    // compile-time positions.  Same arithmetic, same order: bit-identical to the loop.
+    auto spec = [&](auto NQc, auto LASTc) PDWT_AI {
+        {
+            constexpr int NQ = decltype(NQc)::value;
+            constexpr bool LV = decltype(LASTc)::value;
+            using S = CascInvSpec<HLEN, NQ, LV, L3>;
+            // stream rows at which the image wraps, for the (only) waves whose rows do: the last wave of a bottom workgroup
+            constexpr int WR3 = NQ / 2 + C, WR2 = NQ, WR1 = 2 * NQ - 2 * C + SHIFT, WRO = 4 * NQ - 6 * C + 3 * SHIFT;
+            const bool bottom = LV && (Q0 + NQ == Nr2);
+            const unsigned w3 = bottom ? end3 : 0u, w2 = bottom ? end2 : 0u, w1 = bottom ? end1 : 0u;
+            const size_t wo = bottom ? (size_t)Nr * Nc : (size_t)0;
+            static_for<S::NSTEPS>([&](auto Ss) {
+                constexpr int st = decltype(Ss)::value;  // step
+                constexpr int p = st % H2;
+                constexpr bool even = L3 && (st & 1) == 0;
+                if constexpr (S::l2act(st)) {
+                    constexpr int s2 = H2 - 1 + st;
+                    constexpr int sl = s2 % H2;
+                    if constexpr (S::adv3(st)) {
+                        if constexpr (st >= 2) asm_wait4<S::wait3(st)>(q3[0], q3[1], q3[2], q3[3]);
+#pragma unroll
+                        for (int j = 0; j < H2 - 1; j++) {
+                            r3av[j] = r3av[j + 1];
+                            r3hd[j] = r3hd[j + 1];
+                        }
+                        r3av[H2 - 1] = v2f{asm_copy(q3[0]), asm_copy(q3[2])};
+                        r3hd[H2 - 1] = v2f{asm_copy(q3[1]), asm_copy(q3[3])};
+                        if constexpr (S::n3(st) != 0) {
+                            constexpr int row = T0 + H2 + st / 2;  // level-(l+2) stream row this load fetches
+                            const unsigned vo = voff3 + o3;
+                            asm volatile("" : "=v"(q3[0]));
+                            asm volatile("" : "=v"(q3[1]));
+                            asm volatile("" : "=v"(q3[2]));
+                            asm volatile("" : "=v"(q3[3]));
+                            asm_load_s(q3[0], b3.A3, vo);
+                            asm_load_s(q3[1], b3.H3, vo);
+                            asm_load_s(q3[2], b3.V3, vo);
+                            asm_load_s(q3[3], b3.D3, vo);
+                            o3 += str3;
+                            if constexpr (row + 1 == WR3) o3 -= w3;
+                        }
+                    }
+                    if constexpr (S::need2(st)) {
+                        float a2 = 0.f;
+                        if constexpr (L3) a2 = a2_from(r3av, r3hd, std::integral_constant<int, even ? 1 : 0>{});
+                        if constexpr (L3) {
+                            if constexpr (st >= 1) asm_wait3<S::wait2(st)>(q2[1], q2[2], q2[3]);
+                        } else {
+                            if constexpr (st >= 1) asm_wait4<S::wait2(st)>(q2[0], q2[1], q2[2], q2[3]);
+                            a2 = asm_copy(q2[0]);
+                        }
+                        r2av[sl] = v2f{a2, asm_copy(q2[2])};
+                        r2hd[sl] = v2f{asm_copy(q2[1]), asm_copy(q2[3])};
+                    } else {
+                        const v4f e = *lds_l2(lds_rd, s2 - NQ);  // from the wave below (its ring warm-up rows)
+                        r2av[sl] = v2f{e.x, e.y};
+                        r2hd[sl] = v2f{e.z, e.w};
+                    }
+                    if constexpr (S::n2(st) != 0) {
+                        const unsigned vo = voff2 + o2;  // stream row s2 + 1
+                        if constexpr (!L3) {
+                            asm volatile("" : "=v"(q2[0]));
+                            asm_load_s(q2[0], b.A2, vo);
+                        }
+                        asm volatile("" : "=v"(q2[1]));
+                        asm volatile("" : "=v"(q2[2]));
+                        asm volatile("" : "=v"(q2[3]));
+                        asm_load_s(q2[1], b.H2, vo);
+                        asm_load_s(q2[2], b.V2, vo);
+                        asm_load_s(q2[3], b.D2, vo);
+                        o2 += str2;
+                        if constexpr (s2 + 2 == WR2) o2 -= w2;
+                    }
+                }
+                static_for<2>([&](auto I) {
+                    constexpr int idx = decltype(I)::value;
+                    constexpr int r1 = 2 * st + idx;
+                    constexpr int sl = r1 % H2;
+                    if constexpr (S::l2act(st)) {
+                        const v2f a01 = own_pair(synth_col(r2av, r2hd, std::integral_constant<int, p % H2>{}, std::integral_constant<int, 1 - idx>{}));
+                        if constexpr (st >= 1) asm_wait3<S::wait1(st, idx)>(q1[idx][0], q1[idx][1], q1[idx][2]);
+                        ra[sl] = a01;
+                        rh[sl] = asm_copy(q1[idx][0]);
+                        rv[sl] = asm_copy(q1[idx][1]);
+                        rd[sl] = asm_copy(q1[idx][2]);
+                        if constexpr (S::n1(st) != 0) {
+                            const unsigned vo = voff1 + o1;  // stream row r1 + 2
+                            asm volatile("" : "=v"(q1[idx][0]));
+                            asm volatile("" : "=v"(q1[idx][1]));
+                            asm volatile("" : "=v"(q1[idx][2]));
+                            asm_load_s(q1[idx][0], b.H1, vo);
+                            asm_load_s(q1[idx][1], b.V1, vo);
+                            asm_load_s(q1[idx][2], b.D1, vo);
+                            o1 += str1;
+                            if constexpr (r1 + 3 == WR1) o1 -= w1;
+                        }
+                        if constexpr (r1 < H2 - 1) {
+                            if (kw > 0) {
+                                *lds_l1(lds_wr, r1, 0) = v4f{ra[sl].x, ra[sl].y, rh[sl].x, rh[sl].y};
+                                *lds_l1(lds_wr, r1, 1) = v4f{rv[sl].x, rv[sl].y, rd[sl].x, rd[sl].y};
+                            }
+                        }
+                    } else if constexpr (r1 - S::NP < H2 - 1) {
+                        const v4f e0 = *lds_l1(lds_rd, r1 - S::NP, 0), e1 = *lds_l1(lds_rd, r1 - S::NP, 1);
+                        ra[sl] = v2f{e0.x, e0.y};
+                        rh[sl] = v2f{e0.z, e0.w};
+                        rv[sl] = v2f{e1.x, e1.y};
+                        rd[sl] = v2f{e1.z, e1.w};
+                    }
+                    if constexpr (S::own(st, idx)) {
+                        constexpr int ws = r1 - (H2 - 1);
+                        static_for<2>([&](auto Pq) {
+                            constexpr int par = decltype(Pq)::value;  // first the row with tap parity 1, then parity 0
+                            constexpr int g = 2 * ws + par;            // the wave's g-th output row
+                            // (one output row at a time: four interleaved row syntheses do not fit the 128 registers of a 16-wave workgroup)
+                            __builtin_amdgcn_sched_barrier(0);
+                            emit(std::integral_constant<int, (r1 + 1) % H2>{}, std::integral_constant<int, 1 - par>{}, std::true_type{}, g);
+                            if constexpr (g + 1 == WRO) op -= wo;
+                            __builtin_amdgcn_sched_barrier(0);
+                        });
+                    }
+                });
+                if constexpr (st < XS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef PDWT_CASC_TRACE
+                if constexpr (st == H2 - 1) CASC_TRACE(3);
+                if constexpr (st == 2 * H2 - 1) CASC_TRACE(4);
+#endif
+            });
+        }
+    };
+    auto epilogue = [&]() PDWT_AI {
+        CASC_TRACE(5);  // loop left
+#ifdef PDWT_CASC_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        CASC_TRACE(6);  // everything this wave issued has retired
+        CASC_TRACE_STORE(trash + kCascTraceOff, blockIdx.x * W + kw, ((unsigned long long)nsteps << 32) | (unsigned)nQ);
+    };
+    // The wave programs live in a kernel of their own (SPEC): next to the loop in ONE kernel, hipcc's control-flow structuriser chains the
+    // arms (arm 1 -> flag -> arm 2 ... -> loop) and the register allocator then keeps every arm's entry state alive, in scratch, around the
+    // others -- spills of row registers whose loads are in flight included.  Every arm but the last ends the program itself (s_endpgm, not a
+    // return to a common exit) for the same reason.
+    if constexpr (SPEC) {
+        static_assert(W == 16, "wave programs exist for the 16-wave workgroups");
+        const int variant = __builtin_amdgcn_readfirstlane(last ? 3 : (nQ == 6 ? 2 : 1));
+        if (variant == 1) {
+            spec(std::integral_constant<int, 4>{}, std::false_type{});
+            epilogue();
+            __builtin_amdgcn_endpgm();
+        }
+        if (variant == 2) {
+            spec(std::integral_constant<int, 6>{}, std::false_type{});
+            epilogue();
+            __builtin_amdgcn_endpgm();
+        }
+        spec(std::integral_constant<int, 4>{}, std::true_type{});
+        epilogue();
+    } else {
     for (int sb = 0;; sb++) {
         bool fin = false;
         static_for<H2>([&](auto Pp) {
@@ -459,23 +665,24 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
 #endif
         if (fin) break;
     }
-    CASC_TRACE(5);  // loop left
-    asm_drain1(q3[0]);
-    asm_drain1(q3[1]);
-    asm_drain1(q3[2]);
-    asm_drain1(q3[3]);
-    asm_drain1(q2[0]);
-    asm_drain1(q2[1]);
-    asm_drain1(q2[2]);
-    asm_drain1(q2[3]);
-    static_for<2>([&](auto K) {
-        constexpr int k = decltype(K)::value;
-        asm_drain1(q1[k][0]);
-        asm_drain1(q1[k][1]);
-        asm_drain1(q1[k][2]);
-    });
-    CASC_TRACE(6);  // everything this wave issued has retired
-    CASC_TRACE_STORE(trash + kCascTraceOff, blockIdx.x * W + kw, ((unsigned long long)nsteps << 32) | (unsigned)nQ);
+    {
+        asm_drain1(q3[0]);
+        asm_drain1(q3[1]);
+        asm_drain1(q3[2]);
+        asm_drain1(q3[3]);
+        asm_drain1(q2[0]);
+        asm_drain1(q2[1]);
+        asm_drain1(q2[2]);
+        asm_drain1(q2[3]);
+        static_for<2>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            asm_drain1(q1[k][0]);
+            asm_drain1(q1[k][1]);
+            asm_drain1(q1[k][2]);
+        });
+    }
+        epilogue();
+    }
 }
 
 // =================================================================================================
@@ -520,13 +727,19 @@ static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* o
     }
     if (!W) return 1;
     const int nwg = gy * strips;
-    const CascMap cm = {idiv_up(nwg, 8), strips, gy};
+    const CascMap cm = {idiv_up(nwg, 8), strips, gy, 0};
     const dim3 grid((unsigned)(8 * cm.cpx));
     const size_t lds = lds_bytes(W);
     void (*k)(CascInvBands, CascInv3B, float*, int, int, int, float*, CascMap, Taps2<float>);
     k = (W == 4) ? k_inv2d_casc3<HLEN, 4, L3> : (W == 8) ? k_inv2d_casc3<HLEN, 8, L3> : (W == 12) ? k_inv2d_casc3<HLEN, 12, L3> : k_inv2d_casc3<HLEN, 16, L3>;
+    // the straight-line wave programs (kernel form SPEC) exist for waves of 4 or 6 level-(l+1) rows whose workgroup's last wave has 4:
+    // the kernel's split, replayed on the two chunk sizes that occur (C2: 36 or 37 row pairs over 16 waves)
+    bool spec = W == 16 && ((knob(KN_CASC_SPEC) >> 1) & 1) && H2 <= 4;
+    for (int Rp : {np / gy, idiv_up(np, gy)}) spec = spec && (Rp / 16 == 2);
+    if (spec) k = k_inv2d_casc3<HLEN, 16, L3, true>;
     if (lds > 64 * 1024) {  // opt-in once per (kernel, device), not per launch
-        const int rc = (W == 4) ? lds_opt_in<k_inv2d_casc3<HLEN, 4, L3>>() : (W == 8) ? lds_opt_in<k_inv2d_casc3<HLEN, 8, L3>>() : (W == 12) ? lds_opt_in<k_inv2d_casc3<HLEN, 12, L3>>() : lds_opt_in<k_inv2d_casc3<HLEN, 16, L3>>();
+        const int rc = spec ? lds_opt_in<k_inv2d_casc3<HLEN, 16, L3, true>>()
+                       : (W == 4) ? lds_opt_in<k_inv2d_casc3<HLEN, 4, L3>>() : (W == 8) ? lds_opt_in<k_inv2d_casc3<HLEN, 8, L3>>() : (W == 12) ? lds_opt_in<k_inv2d_casc3<HLEN, 12, L3>>() : lds_opt_in<k_inv2d_casc3<HLEN, 16, L3>>();
         if (rc != PDWT_OK) return rc;
     }
     KTimer kt(K_INV2D_CASC, true);
