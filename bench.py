@@ -241,7 +241,18 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
     levels_eff = W.info.nlevels
     nbatch = cfg.get("batch", 1)
     Ws = [W]
-    for bi in range(1, nbatch):  # the other images of the batch: distinct data, private instances (image + bands + scratch each)
+    IB = None
+    if nbatch > 1 and not getattr(args, "batch_instances", False):
+        # the product's batched entry (include/wt_batch.h WaveletsImages / pdwt_batch2d_*): all images in ONE launch per kernel of the
+        # level plan (gridDim.y = image) -- at this size the two cascade launches + the level-3 launch of the single image
+        stack = torch.empty(nbatch, cfg["Nr"], cfg["Nc"], device="cuda", dtype=tdt)
+        for bi in range(nbatch):
+            g.manual_seed(1234 + rank + 1000 * bi)
+            stack[bi] = torch.rand(cfg["Nr"], cfg["Nc"], device="cuda", dtype=tdt, generator=g) * 255.0
+        torch.cuda.synchronize()
+        IB = pdwt_amd_mod().ImageBatch(stack, cfg["wname"], cfg["levels"])
+        del stack
+    for bi in range(1, nbatch if IB is None else 1):  # the other images of the batch: distinct data, private instances (image + bands + scratch each)
         g.manual_seed(1234 + rank + 1000 * bi)
         xi = torch.rand(cfg["Nr"], cfg["Nc"], device="cuda", dtype=tdt, generator=g) * 255.0
         torch.cuda.synchronize()
@@ -249,7 +260,11 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
                                           shape=(cfg["Nr"], cfg["Nc"]), device_ptr=xi.data_ptr()))
         del xi
 
-    if nbatch > 1:
+    if IB is not None:
+        def step():
+            IB.forward()
+            IB.inverse()
+    elif nbatch > 1:
         def step():
             for Wi in Ws:
                 Wi.forward()
@@ -623,6 +638,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other configs (other_configs)")
+    ap.add_argument("--batch-instances", action="store_true", help="c2_batch: cycle 16 private Wavelets instances (one image per launch) instead of the ImageBatch entry")
     ap.add_argument("--settle-ms", type=float, default=150.0, help="untimed load before the warm-up steps (clock settling)")
     args = ap.parse_args()
 

@@ -117,6 +117,9 @@ class Wavelets {
      * reduction before it reads the first one and adds the doubles. */
     void norm1_begin();
     double norm1_end();
+    /* ADDITION: 1 once set_filters_forward() / set_filters_inverse() has replaced the bank of `wname` (wt_batch.h: a batch whose
+     * members do not all run the named bank any more is transformed image by image) */
+    int custom_filters() const;
 
   private:
     /* per-instance filter bank (the reference keeps it in process-global constant memory, so two

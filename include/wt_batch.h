@@ -117,7 +117,10 @@ class WaveletsImages {
     {
         for (int b = 0; b < B; b++) {
             img.push_back(new Wavelets(imgs + (size_t)b * Nr * Nc, Nr, Nc, wname, levels, memisonhost, 1, 0, 0, 2));
-            img.back()->set_norm_cache(0); /* the batched launches write the bands behind the instances' backs */
+            /* the batched launches write the bands behind the instances' backs: no norm kept from a threshold pass, whatever
+             * set_norm_cache() / PDWT_NORM_IN_THRESHOLD say later (taking a raw band pointer switches that shortcut off for good) */
+            img.back()->set_norm_cache(0);
+            if (img.back()->state != W_CREATION_ERROR) (void)img.back()->coeff_int_ptr(0);
         }
 #ifndef DOUBLEPRECISION
         if (ok()) {
@@ -147,10 +150,17 @@ class WaveletsImages {
         return !img.empty();
     }
     bool batched() const { return batch_ != NULL; } /* one launch per level over all images */
+    /* the one-launch form runs the bank of `wname` on every image: not for a batch in which set_filters_*() changed a member's bank */
+    bool named_bank() const
+    {
+        for (size_t b = 0; b < img.size(); b++)
+            if (img[b]->custom_filters()) return false;
+        return true;
+    }
     void forward()
     {
 #ifndef DOUBLEPRECISION
-        if (batch_ && pdwt_batch2d_forward_f32(batch_, &bank_) == 0) {
+        if (batch_ && named_bank() && pdwt_batch2d_forward_f32(batch_, &bank_) == 0) {
             for (size_t b = 0; b < img.size(); b++) img[b]->state = W_FORWARD;
             return;
         }
@@ -162,7 +172,7 @@ class WaveletsImages {
 #ifndef DOUBLEPRECISION
         bool all_fwd = true;
         for (size_t b = 0; b < img.size(); b++) all_fwd = all_fwd && img[b]->state != W_INVERSE && img[b]->state != W_CREATION_ERROR;
-        if (batch_ && all_fwd && pdwt_batch2d_inverse_f32(batch_, &bank_) == 0) {
+        if (batch_ && all_fwd && named_bank() && pdwt_batch2d_inverse_f32(batch_, &bank_) == 0) {
             for (size_t b = 0; b < img.size(); b++) img[b]->state = W_INVERSE;
             return;
         }

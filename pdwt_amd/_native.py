@@ -154,6 +154,9 @@ def host(dtype):
         L.pdwt_wavelets_norm1_f64.restype = C.c_double
         L.pdwt_wavelets_norm1_f64.argtypes = [vp]
         L.pdwt_wavelets_set_norm_cache.argtypes = [vp, ci]
+        L.pdwt_wavelets_norm1_begin.argtypes = [vp]
+        L.pdwt_wavelets_norm1_end.restype = C.c_double
+        L.pdwt_wavelets_norm1_end.argtypes = [vp]
         L.pdwt_wavelets_norm2sq.restype = ct
         L.pdwt_wavelets_norm2sq.argtypes = [vp]
         for n in ("hard_threshold", "group_soft_threshold"):

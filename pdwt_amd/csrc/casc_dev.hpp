@@ -28,10 +28,16 @@ struct CascMap {
     int cpx;     // W == 1: chunk rows per XCD (all 8 XCDs get the same number); W > 1: workgroups per XCD
     int strips;  // strips per chunk row
     int gy;      // W > 1: workgroup-chunk rows (gy * strips workgroups in all)
-    int flags;   // bit 0: waves whose row counts have a straight-line instantiation run it (knob casc_spec)
+    int flags;   // (unused)
+    const void* tbl;  // batched launch (gridDim.y = images): device array of CascBatchF / CascBatchI, one entry per image; NULL = one image
 };
 struct CascBands {
     float *H1, *V1, *D1, *A2, *H2, *V2, *D2;
+};
+// per-image pointers of a batched forward cascade launch (pdwt_batch2d_*, dwt.hip)
+struct CascBatchF {
+    const float* in;
+    CascBands b;
 };
 
 template <int HLEN>
@@ -52,6 +58,15 @@ struct CascInvGeom {
 };
 struct CascInvBands {
     const float *A2, *H2, *V2, *D2, *H1, *V1, *D1;
+};
+struct CascInv3B {
+    const float *A3, *H3, *V3, *D3;
+};
+// per-image pointers of a batched inverse cascade launch
+struct CascBatchI {
+    CascInvBands b;
+    CascInv3B b3;
+    float* out;
 };
 
 
@@ -82,7 +97,7 @@ constexpr size_t kCascTraceOff = 1u << 20;
 // dwt_casc_inv3.hip: three levels, all streamed (A3 != NULL), or two; hlen 4 and 8; 1 = not taken
 int inv2d_casc3_f32(const float* A2, const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1,
                     const float* A3, const float* H3, const float* V3, const float* D3, float* out, float* trash, int nr, int nc, int hlen,
-                    const Taps2<float>& f);
+                    const Taps2<float>& f, const CascBatchI* d_tbl = nullptr, int nimg = 1);
 
 int inv2d_cascw_f32(const float* A2, const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1,
                     const float* A3, const float* H3, const float* V3, const float* D3, float* out, float* trash, int nr, int nc, int hlen,

@@ -90,6 +90,10 @@ inline int lds_opt_in()
     return PDWT_OK;
 }
 
+// The same for kernels that are only known as a pointer at the call site (templates instantiated over many lengths): one driver
+// call per (kernel, device), remembered in a small table (runtime.hip); every later launch is a lookup.
+int lds_opt_in_ptr(const void* kernel);
+
 // ---- in-kernel clock probe (pdwt_clock_probe_*, runtime.hip) ----------------------------------------------------
 // Workgroup 0 of a probed launch stores (s_memtime, s_memrealtime) when it starts and when it ends: the shader-clock count over
 // the constant 100 MHz count = the clock the kernel actually ran at, to be compared with what amdsmi reports for the same

@@ -430,7 +430,7 @@ __global__ __launch_bounds__(kThreads) void k_syn_rows(const T* __restrict__ a, 
 template <typename K>
 static int set_lds(K kernel, size_t bytes)
 {
-    if (bytes > 64 * 1024) PDWT_HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (bytes > 64 * 1024) return lds_opt_in_ptr((const void*)kernel);  // (a driver call the first time only, never on the steady-state enqueue path)
     return PDWT_OK;
 }
 
@@ -857,15 +857,21 @@ struct Batch2D {
     int lev_nr[33], lev_nc[33];
     StreamBatchF* d_fwd;  // [level][image]
     StreamBatchI* d_inv;  // [level][image]
+    // the two finest levels (forward) / the three finest (inverse; two when the transform has two) through the cascade kernels, all
+    // images in one launch (gridDim.y = image): per-image pointers of those launches, and image 0's for the launchers' checks
+    CascBatchF* d_cf;
+    CascBatchI* d_ci;
+    CascBatchF cf0;
+    CascBatchI ci0;
+    float* trash0;
 };
 
 static Batch2D* batch2d_create(int nimg, float* const* d_images, float** const* d_coeffs, float* const* d_tmps, pdwt_info w, int hlen)
 {
     if (nimg < 1 || nimg > 65535 || !d_images || !d_coeffs || !d_tmps || w.ndims != 2 || w.do_swt || w.nlevels < 1 || w.nlevels > 32) return nullptr;
     if (force_twopass()) return nullptr;
-    // larger images belong to the cascade kernels, one image per launch (16 x 4096^2 db4 L3: 72.5 us per image there, 88.9 through
-    // the per-level kernels of this path; 32 x 2048^2: 31.0 against 23.7 here)
-    if ((long long)w.Nr * w.Nc > 2048LL * 2048) return nullptr;
+    // (images of 2048^2 and more take the cascade kernels for their finest levels, see batch2d_forward / batch2d_inverse; the tables of
+    // the per-level kernels are built for every level all the same: they are the fallback when a cascade launcher declines)
     // every level must be inside the streaming path, in both directions
     int nr = w.Nr, nc = w.Nc;
     for (int lev = 0; lev < w.nlevels; lev++) {
@@ -882,6 +888,9 @@ static Batch2D* batch2d_create(int nimg, float* const* d_images, float** const* 
     B->trash_floats = probe.trash_floats;
     B->d_fwd = nullptr;
     B->d_inv = nullptr;
+    B->d_cf = nullptr;
+    B->d_ci = nullptr;
+    B->trash0 = nullptr;
     if (hipGetDevice(&B->dev) != hipSuccess) {
         delete B;
         return nullptr;
@@ -930,20 +939,69 @@ static Batch2D* batch2d_create(int nimg, float* const* d_images, float** const* 
     const size_t bf = hf.size() * sizeof(StreamBatchF), bi = hi.size() * sizeof(StreamBatchI);
     B->d_fwd = (StreamBatchF*)pdwt_malloc(bf);
     B->d_inv = (StreamBatchI*)pdwt_malloc(bi);
-    if (!B->d_fwd || !B->d_inv || pdwt_memcpy_h2d(B->d_fwd, hf.data(), bf) != PDWT_OK || pdwt_memcpy_h2d(B->d_inv, hi.data(), bi) != PDWT_OK) {
+    bool ok = B->d_fwd && B->d_inv && pdwt_memcpy_h2d(B->d_fwd, hf.data(), bf) == PDWT_OK && pdwt_memcpy_h2d(B->d_inv, hi.data(), bi) == PDWT_OK;
+    // cascade tables (two levels and more): the forward pair (0, 1) writes its A2 where level 1 of the per-level chain does, the inverse
+    // reads the approximation that enters level 2 (three levels in one launch) or level 1 (a two-level transform)
+    if (ok && L >= 2) {
+        std::vector<CascBatchF> hcf((size_t)nimg);
+        std::vector<CascBatchI> hci((size_t)nimg);
+        for (int b = 0; b < nimg; b++) {
+            float* const* c = d_coeffs[b];
+            hcf[b] = CascBatchF{d_images[b], CascBands{c[1], c[2], c[3], hf[(size_t)1 * nimg + b].cA, c[4], c[5], c[6]}};
+            hci[b].b = CascInvBands{L == 2 ? hi[(size_t)1 * nimg + b].cA : nullptr, c[4], c[5], c[6], c[1], c[2], c[3]};
+            hci[b].b3 = (L >= 3) ? CascInv3B{hi[(size_t)2 * nimg + b].cA, c[7], c[8], c[9]} : CascInv3B{nullptr, nullptr, nullptr, nullptr};
+            hci[b].out = d_images[b];
+        }
+        B->cf0 = hcf[0];
+        B->ci0 = hci[0];
+        Scratch<float> s0(d_tmps[0], w.Nr, w.Nc, 2);
+        B->trash0 = s0.t1_is_trash ? (float*)s0.t1 : nullptr;
+        const size_t cf = hcf.size() * sizeof(CascBatchF), ci = hci.size() * sizeof(CascBatchI);
+        B->d_cf = (CascBatchF*)pdwt_malloc(cf);
+        B->d_ci = (CascBatchI*)pdwt_malloc(ci);
+        ok = B->d_cf && B->d_ci && pdwt_memcpy_h2d(B->d_cf, hcf.data(), cf) == PDWT_OK && pdwt_memcpy_h2d(B->d_ci, hci.data(), ci) == PDWT_OK;
+    }
+    if (!ok) {
         pdwt_free(B->d_fwd);
         pdwt_free(B->d_inv);
+        pdwt_free(B->d_cf);
+        pdwt_free(B->d_ci);
         delete B;
         return nullptr;
     }
     return B;
 }
 
+// the launches of a batch run on the device its images live on, whatever device is current (Wavelets methods switch to their own
+// device the same way; WaveletsBatch drives several devices from one thread)
+struct Batch2DDev {
+    int prev = -1;
+    bool switched = false;
+    explicit Batch2DDev(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~Batch2DDev()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
 static int batch2d_forward(Batch2D* B, const pdwt_filters_f32* filt)
 {
     if (!B || !filt || filt->hlen != B->w.hlen) return PDWT_EINVAL;
+    Batch2DDev on_dev(B->dev);
     const Taps2<float> f = taps_fwd<float>(filt);
-    for (int lev = 0; lev < B->w.nlevels; lev++) {
+    int lev0 = 0;
+    if (B->d_cf && B->trash0) {
+        // levels 0 and 1 of every image in one cascade launch (gridDim.y = image); 1 = geometry outside that path
+        const CascBands& b = B->cf0.b;
+        const int rc = fwd2d_casc_f32(B->cf0.in, b.H1, b.V1, b.D1, b.A2, b.H2, b.V2, b.D2, B->trash0, B->lev_nr[0], B->lev_nc[0], B->w.hlen, f,
+                                      B->d_cf, B->nimg);
+        if (rc < 0) return rc;
+        if (rc == PDWT_OK) lev0 = 2;
+    }
+    for (int lev = lev0; lev < B->w.nlevels; lev++) {
         const int rc = fwd2d_stream_batch_f32(B->d_fwd + (size_t)lev * B->nimg, B->nimg, B->trash_floats, B->lev_nr[lev], B->lev_nc[lev], B->w.hlen, f);
         if (rc != PDWT_OK) return rc < 0 ? rc : PDWT_EINVAL;
     }
@@ -953,9 +1011,29 @@ static int batch2d_forward(Batch2D* B, const pdwt_filters_f32* filt)
 static int batch2d_inverse(Batch2D* B, const pdwt_filters_f32* filt)
 {
     if (!B || !filt || filt->hlen != B->w.hlen) return PDWT_EINVAL;
+    Batch2DDev on_dev(B->dev);
     const Taps2<float> f = taps_inv<float>(filt);
-    for (int i = B->w.nlevels - 1; i >= 0; i--) {
-        const int rc = inv2d_stream_batch_f32(B->d_inv + (size_t)i * B->nimg, B->nimg, B->lev_nr[i + 1], B->lev_nc[i + 1], B->w.hlen, f);
+    // the finest three levels (two for a two-level transform) of every image in one cascade launch, when that path takes the geometry;
+    // decided BEFORE the coarser levels run (they must not be run twice), by the same test the launcher applies
+    const int L = B->w.nlevels;
+    const int ncasc = (L >= 3) ? 3 : 2;
+    bool casc = B->d_ci && B->trash0 && L >= 2 && knob(KN_CASC) == 1 && knob(KN_CASC_IWG) != 1 && knob(KN_CASC_L3) == 1 && stream_enabled() &&
+                !((long long)knob(KN_CASC_MIN) > (long long)B->lev_nr[0] * B->lev_nc[0]);
+    int next = L - 1;  // next level the per-level kernels would run
+    for (; next >= (casc ? ncasc : 0); next--) {
+        const int rc = inv2d_stream_batch_f32(B->d_inv + (size_t)next * B->nimg, B->nimg, B->lev_nr[next + 1], B->lev_nc[next + 1], B->w.hlen, f);
+        if (rc != PDWT_OK) return rc < 0 ? rc : PDWT_EINVAL;
+    }
+    if (casc) {
+        const CascInvBands& b = B->ci0.b;
+        const CascInv3B& b3 = B->ci0.b3;
+        const int rc = inv2d_casc3_f32(b.A2, b.H2, b.V2, b.D2, b.H1, b.V1, b.D1, b3.A3, b3.H3, b3.V3, b3.D3, B->ci0.out, B->trash0, B->lev_nr[0],
+                                       B->lev_nc[0], B->w.hlen, f, B->d_ci, B->nimg);
+        if (rc < 0) return rc;
+        if (rc == PDWT_OK) return PDWT_OK;
+    }
+    for (; next >= 0; next--) {  // (the cascade launcher declined: the per-level kernels finish the job)
+        const int rc = inv2d_stream_batch_f32(B->d_inv + (size_t)next * B->nimg, B->nimg, B->lev_nr[next + 1], B->lev_nc[next + 1], B->w.hlen, f);
         if (rc != PDWT_OK) return rc < 0 ? rc : PDWT_EINVAL;
     }
     return PDWT_OK;
@@ -978,6 +1056,8 @@ void pdwt_batch2d_destroy(void* batch)
     if (!B) return;
     pdwt_free(B->d_fwd);
     pdwt_free(B->d_inv);
+    pdwt_free(B->d_cf);
+    pdwt_free(B->d_ci);
     delete B;
 }
 int pdwt_debug_set(const char* key, int value) { return pdwt::knob_set(key, value); }

@@ -511,7 +511,7 @@ static bool fill_bands(Bands1D<T>& b, T** c, const pdwt_info& w)
 template <typename K>
 static int set_lds(K kernel, size_t bytes)
 {
-    if (bytes > 64 * 1024) PDWT_HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (bytes > 64 * 1024) return lds_opt_in_ptr((const void*)kernel);  // (a driver call the first time only, never on the steady-state enqueue path)
     return PDWT_OK;
 }
 

@@ -79,7 +79,7 @@ struct CascSpec {
 //           extra loads, no recomputation, and the waves of a workgroup are balanced by giving the last one fewer rows.
 // SPEC = true: the kernel consists of the straight-line wave programs only (the host launches it when every wave of the geometry has one)
 template <int HLEN, int NV, int W, bool SPEC = false>
-__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const float* __restrict__ in, CascBands b, int Nr, int Nc, int VL,
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const float* in, CascBands b, int Nr, int Nc, int VL,
                                                                        float* __restrict__ trash, CascMap cm, TapsLH f)
 {
     using G = CascGeom<HLEN>;
@@ -87,6 +87,13 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     CASC_TRACE_DECL;
     CASC_TRACE(0);
+    if constexpr (W > 1) {
+        if (cm.tbl) {  // batched launch: this workgroup's image (uniform -> scalar loads)
+            const CascBatchF e = static_cast<const CascBatchF*>(cm.tbl)[blockIdx.y];
+            in = e.in;
+            b = e.b;
+        }
+    }
     const int lane = threadIdx.x & 63;
     const int Nc2 = Nc >> 1, Nr2 = Nr >> 1, Nr4 = Nr >> 2, Nc4 = Nc >> 2;
     // the wave index is uniform, but only readfirstlane tells the compiler: everything derived from it (rows, row
@@ -801,7 +808,7 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
 static bool casc_enabled() { return knob(KN_CASC) == 1; }
 
 template <int HLEN>
-static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, int nr, int nc, const Taps2<float>& f2)
+static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, int nr, int nc, const Taps2<float>& f2, const CascBatchF* d_tbl, int nimg)
 {
     TapsLH f;
     for (int k = 0; k < PDWT_MAX_FILTER_WIDTH; k++) f.t[k] = v2f{f2.a[k], f2.b[k]};
@@ -829,8 +836,8 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
         while (gy > 1 && (nr4 / gy) / W < HLEN / 2) gy--;  // every wave needs >= HLEN/2 level-2 rows (see the kernel)
         if (gy >= 1 && (nr4 / gy) / W >= HLEN / 2) {
             const int nwg = gy * strips;
-            const CascMap cm = {idiv_up(nwg, 8), strips, gy, 0};
-            const dim3 grid((unsigned)(8 * cm.cpx));
+            const CascMap cm = {idiv_up(nwg, 8), strips, gy, 0, d_tbl};
+            const dim3 grid((unsigned)(8 * cm.cpx), (unsigned)(d_tbl ? nimg : 1));
             const size_t lds = (size_t)(W - 1) * REG;  // hand-off regions
             // (HLEN row registers in flight instead of HLEN/2 measured slower in this form too: 24.8 vs 24.6 us at W = 8)
             void (*k)(const float*, CascBands, int, int, int, float*, CascMap, TapsLH);
@@ -860,6 +867,7 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
             return PDWT_OK;
         }
     }
+    if (d_tbl) return 1;  // (the independent-wave kernels have no batched form)
     // ---- independent waves.  chunk rows: a multiple of 8 (one band per XCD), ~PDWT_CASC_WAVES waves in total, at least 4
     // level-2 rows each.  One wave per SIMD (1024) is the optimum: every extra chunk row recomputes 3(hlen-2) input rows of halo
     // (measured 27.2 us @1024, 30.9 @2048, 35 @4096 for 4096^2 db4).
@@ -888,7 +896,7 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
 #endif
 
 int fwd2d_casc_f32(const float* in, float* H1, float* V1, float* D1, float* A2, float* H2, float* V2, float* D2, float* trash, int nr,
-                   int nc, int hlen, const Taps2<float>& f)
+                   int nc, int hlen, const Taps2<float>& f, const CascBatchF* d_tbl, int nimg)
 {
     if (!casc_enabled() || !stream_enabled() || !trash) return 1;
     if ((nr & 3) || (nc & 3) || nc < 256 || nr < 16 * hlen) return 1;
@@ -898,7 +906,7 @@ int fwd2d_casc_f32(const float* in, float* H1, float* V1, float* D1, float* A2, 
     const CascBands b = {H1, V1, D1, A2, H2, V2, D2};
     switch (hlen) {
 #define X(H) \
-    case H: return launch_fwd_casc<H>(in, b, trash, nr, nc, f);
+    case H: return launch_fwd_casc<H>(in, b, trash, nr, nc, f, d_tbl, nimg);
         PDWT_CASC_FWD_HLENS(X)
 #undef X
         default: return 1;

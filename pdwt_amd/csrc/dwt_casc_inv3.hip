@@ -33,10 +33,6 @@ namespace pdwt {
 // whole state passed through scratch)
 #define PDWT_AI __attribute__((always_inline))
 
-struct CascInv3B {
-    const float *A3, *H3, *V3, *D3;
-};
-
 template <int HLEN>
 constexpr int casc_inv3_region_bytes() { return (HLEN / 2 - 1) * 64 * (16 + 32); }
 
@@ -70,7 +66,7 @@ struct CascInvSpec {
 // L3 = false: the same kernel on TWO levels (the A parts of the level-(l+1) rows are loaded like their H, V, D parts; no third ring)
 // SPEC = true: the kernel consists of the straight-line wave programs only (the host launches it when every wave of the geometry has one)
 template <int HLEN, int W, bool L3, bool SPEC = false>
-__global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3B b3, float* __restrict__ out, int Nr, int Nc, int VL,
+__global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3B b3, float* out, int Nr, int Nc, int VL,
                                                          float* __restrict__ trash, CascMap cm, Taps2<float> f)
 {
     using G = CascInvGeom<HLEN>;
@@ -87,6 +83,12 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     CASC_TRACE_DECL;
     CASC_TRACE(0);
+    if (cm.tbl) {  // batched launch: this workgroup's image (uniform -> scalar loads)
+        const CascBatchI e = static_cast<const CascBatchI*>(cm.tbl)[blockIdx.y];
+        b = e.b;
+        b3 = e.b3;
+        out = e.out;
+    }
     const int lane = threadIdx.x & 63;
     const int kw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Nr1 = Nr >> 1, Nc1 = Nc >> 1, Nr2 = Nr >> 2, Nc2 = Nc >> 2, Nr3 = Nr >> 3, Nc3 = Nc >> 3;
@@ -691,7 +693,8 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
 #define PDWT_CHECK_LAUNCH() PDWT_HIP_TRY(hipGetLastError())
 
 template <int HLEN, bool L3>
-static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* out, float* trash, int nr, int nc, const Taps2<float>& f)
+static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* out, float* trash, int nr, int nc, const Taps2<float>& f,
+                            const CascBatchI* d_tbl, int nimg)
 {
     using G = CascInvGeom<HLEN>;
     constexpr int H2 = G::H2, XS = H2 / 2;
@@ -727,8 +730,8 @@ static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* o
     }
     if (!W) return 1;
     const int nwg = gy * strips;
-    const CascMap cm = {idiv_up(nwg, 8), strips, gy, 0};
-    const dim3 grid((unsigned)(8 * cm.cpx));
+    const CascMap cm = {idiv_up(nwg, 8), strips, gy, 0, d_tbl};
+    const dim3 grid((unsigned)(8 * cm.cpx), (unsigned)(d_tbl ? nimg : 1));
     const size_t lds = lds_bytes(W);
     void (*k)(CascInvBands, CascInv3B, float*, int, int, int, float*, CascMap, Taps2<float>);
     k = (W == 4) ? k_inv2d_casc3<HLEN, 4, L3> : (W == 8) ? k_inv2d_casc3<HLEN, 8, L3> : (W == 12) ? k_inv2d_casc3<HLEN, 12, L3> : k_inv2d_casc3<HLEN, 16, L3>;
@@ -752,7 +755,7 @@ static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* o
 // length is outside this path (the caller falls back to dwt_casc_invw.hip).
 int inv2d_casc3_f32(const float* A2, const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1,
                     const float* A3, const float* H3, const float* V3, const float* D3, float* out, float* trash, int nr, int nc, int hlen,
-                    const Taps2<float>& f)
+                    const Taps2<float>& f, const CascBatchI* d_tbl, int nimg)
 {
     const bool l3 = A3 != nullptr;
     if ((nr & 7) || (nc & 7) || nc < 256 || nr < 32 * hlen) return 1;
@@ -762,8 +765,8 @@ int inv2d_casc3_f32(const float* A2, const float* H2, const float* V2, const flo
     const CascInvBands b = {A2, H2, V2, D2, H1, V1, D1};
     const CascInv3B b3 = {A3, H3, V3, D3};
     switch (hlen) {
-        case 4: return l3 ? launch_inv_casc3<4, true>(b, b3, out, trash, nr, nc, f) : launch_inv_casc3<4, false>(b, b3, out, trash, nr, nc, f);
-        case 8: return l3 ? launch_inv_casc3<8, true>(b, b3, out, trash, nr, nc, f) : launch_inv_casc3<8, false>(b, b3, out, trash, nr, nc, f);
+        case 4: return l3 ? launch_inv_casc3<4, true>(b, b3, out, trash, nr, nc, f, d_tbl, nimg) : launch_inv_casc3<4, false>(b, b3, out, trash, nr, nc, f, d_tbl, nimg);
+        case 8: return l3 ? launch_inv_casc3<8, true>(b, b3, out, trash, nr, nc, f, d_tbl, nimg) : launch_inv_casc3<8, false>(b, b3, out, trash, nr, nc, f, d_tbl, nimg);
         default: return 1;
     }
 }

@@ -1,5 +1,7 @@
 // runtime.hip -- device / memory / stream / event plumbing of the C-ABI (include/pdwt_hip.h).
 // Replaces the bare CUDA runtime calls of the reference's class (src/wt.cu:117-130,421-468,543-549).
+#include <set>
+#include <utility>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -43,6 +45,20 @@ hipStream_t stream()
         }
     }
     return g_streams[dev];
+}
+
+// ---- > 64 KB of dynamic LDS: opt-in once per (kernel, device) --------------------------------------
+int lds_opt_in_ptr(const void* kernel)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    PDWT_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({kernel, dev})) return PDWT_OK;
+    PDWT_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done.insert({kernel, dev});
+    return PDWT_OK;
 }
 
 // ---- knobs: environment read once, pdwt_debug_set at run time ---------------------------------------

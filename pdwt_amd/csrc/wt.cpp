@@ -72,6 +72,7 @@ struct wstate_t {
     // reference -- d_coeffs is a public member (src/wt.h:25), so the class cannot see a caller's kernel writing a band
     int norm_cache;
     int norm_enqueued;  // norm1_begin() has a reduction in flight into d_sum
+    int custom;         // set_filters_forward / set_filters_inverse replaced the named bank
 };
 static inline void coeffs_changed(void* st)
 {
@@ -436,6 +437,8 @@ static bool norm_in_threshold(const wstate_t* st)
     return v < 0 ? st->norm_cache == 1 : v == 1;
 }
 
+int Wavelets::custom_filters() const { return filters_ ? WS(filters_)->custom : 0; }
+
 void Wavelets::set_norm_cache(int on)
 {
     if (!filters_) return;
@@ -616,6 +619,7 @@ int Wavelets::set_filters_forward(char* filtername, uint len, DTYPE* filter1, DT
     }
     if (!filter1 || !filter2 || len < 1) return -2;
     drop_graphs(filters_);  // recorded launches carry the old taps
+    WS(filters_)->custom = 1;
     if (!do_separable) {  // four len x len kernels (w_set_filters_forward_nonseparable, src/nonseparable.cu:86-95)
         if (filter3 == NULL || filter4 == NULL) {
             puts("ERROR: Wavelets.set_filters_forward(): expected argument 4 and 5 for non-separable filtering");
@@ -647,6 +651,7 @@ int Wavelets::set_filters_inverse(DTYPE* filter1, DTYPE* filter2, DTYPE* filter3
     ON_MY_DEVICE();
     if (!filter1 || !filter2 || !filters_) return -2;
     drop_graphs(filters_);
+    WS(filters_)->custom = 1;
     const int len = winfos.hlen;
     if (!do_separable) {
         if (filter3 == NULL || filter4 == NULL) {

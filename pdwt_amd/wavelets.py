@@ -235,6 +235,14 @@ class Wavelets:
         """Sum of |c| over all bands, in double (pdwt_norm1_as_double_*): shard-combinable."""
         return float(self._L.pdwt_wavelets_norm1_f64(self._h))
 
+    def norm1_begin(self):
+        """Enqueue the reduction of norm1() on the instance's device without waiting for it (include/wt.h: norm1_begin)."""
+        self._L.pdwt_wavelets_norm1_begin(self._h)
+
+    def norm1_end(self):
+        """Wait for the reduction norm1_begin() started and return the sum in double (alone: the same as norm1_f64())."""
+        return float(self._L.pdwt_wavelets_norm1_end(self._h))
+
     def get_image(self):
         out = np.empty(self.shape, dtype=self.dtype)
         n = self._L.pdwt_wavelets_get_image(self._h, out.ctypes.data_as(C.c_void_p))

@@ -1119,7 +1119,10 @@ def test_padded_banks_with_non_finite_samples():
 
 
 @pytest.mark.parametrize("case", [(12, 512, 512, "db4", 3, np.float32), (5, 256, 384, "sym8", 2, np.float32), (3, 1024, 512, "db2", 4, np.float32),
-                                  (4, 250, 250, "db4", 2, np.float32), (3, 256, 256, "db4", 2, np.float64)])
+                                  (4, 250, 250, "db4", 2, np.float32), (3, 256, 256, "db4", 2, np.float64),
+                                  # the cascade kernels with a batch dimension (gridDim.y = image): the C2 geometry (straight-line wave
+                                  # programs), a two-level transform, and four levels (the coarsest one on the per-level kernels)
+                                  (3, 4096, 4096, "db4", 3, np.float32), (3, 2048, 2048, "db4", 2, np.float32), (3, 2048, 4096, "db2", 4, np.float32)])
 def test_image_batch_one_launch_per_level(case):
     """include/wt_batch.h WaveletsImages / pdwt_batch2d_*: a batch of equally sized images, every level of ALL images in one launch
     of the streaming level kernels (gridDim.y = image).  Bands and reconstructions equal the per-image transforms bit for bit
