@@ -121,6 +121,10 @@ void pdwt_batch2d_destroy(void* batch);
  * launch records the shader-clock counter and the 100 MHz real-time counter at its start and end.  slot = direction * 8 + size
  * class (forward 0, inverse 8; class 0 = 16384 rows, 1 = 8192, 2 = 4096, ...): the last launch of that kind.  shader_mhz = the
  * clock the workgroup actually ran at, span_us its lifetime; 0 when nothing was recorded.  Synchronises the stream. */
+/* Bandwidth probe (measurement only, bench.py roofline.copy_ceiling): one launch on the library stream that copies `bytes` from src to dst
+ * (mode 0), only reads src (1; dst needs 16 valid bytes) or only writes dst (2) with 16-byte accesses, eight in flight per lane, one
+ * contiguous chunk per workgroup.  Time it with pdwt_event_*. */
+int pdwt_probe_bandwidth(const void* src, void* dst, size_t bytes, int mode);
 int pdwt_clock_probe_enable(int on);
 int pdwt_clock_probe_read(int slot, double* shader_mhz, double* span_us);
 /* diagnostic: enable(2) / enable(3) make EVERY workgroup of the forward / inverse launches record (the last launch wins);

@@ -361,6 +361,45 @@ int pdwt_graph_destroy(void* exec)
     return PDWT_OK;
 }
 
+// ---- first-party bandwidth probe (bench.py: roofline.copy_ceiling; tools/probes/hbm_ceiling.hip is the full sweep) ----------------
+// mode 0: copy src -> dst, 1: read src only, 2: write dst only.  16 bytes per lane and instruction, eight in flight per lane, every
+// workgroup owns one contiguous chunk (the walk that streams best on this chip: profiles/r04_hbm_ceiling.md).  Runs on the library
+// stream; the caller times it with pdwt_event_*.
+namespace {
+typedef float probe_v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_bw_probe(const probe_v4f* __restrict__ in, probe_v4f* __restrict__ out, size_t n4, int mode)
+{
+    const size_t G = gridDim.x, per = (n4 / 256 + G - 1) / G;  // 4 KiB blocks per workgroup
+    probe_v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t k = 0; k < per; k += 8) {
+        probe_v4f r[8];
+        size_t idx[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            idx[u] = (blockIdx.x * per + k + u) * 256 + threadIdx.x;
+            if (mode != 2) r[u] = in[idx[u] < n4 ? idx[u] : threadIdx.x];
+            else r[u] = probe_v4f{1.f, 2.f, 3.f, (float)u};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (mode == 1) acc += r[u];
+            else if (idx[u] < n4) out[idx[u]] = r[u];
+        }
+    }
+    if (mode == 1 && acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc;  // (never true: keeps the loads alive)
+}
+}  // namespace
+int pdwt_probe_bandwidth(const void* src, void* dst, size_t bytes, int mode)
+{
+    if (mode < 0 || mode > 2 || bytes < 4096 || (mode != 2 && !src) || !dst) return PDWT_EINVAL;
+    int dev = 0, ncu = 256;
+    PDWT_HIP_TRY(hipGetDevice(&dev));
+    PDWT_HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    hipLaunchKernelGGL(k_bw_probe, dim3((unsigned)(8 * ncu)), dim3(256), 0, pdwt::stream(), (const probe_v4f*)src, (probe_v4f*)dst, bytes / 16, mode);
+    PDWT_HIP_TRY(hipGetLastError());
+    return PDWT_OK;
+}
+
 int pdwt_clock_probe_enable(int on)
 {
     g_probe_on = on == 1;

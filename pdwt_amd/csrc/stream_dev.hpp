@@ -144,17 +144,23 @@ __device__ __forceinline__ void asm_store(float* p, v4f d) { asm volatile("globa
 // (lanes that own no output are switched off instead of being redirected); a partially masked VMEM instruction
 // still counts as one in vmcnt, so the hand-counted waits stay exact.
 typedef unsigned long long lanemask_t;
+// (experiments only, tools/variant_lib.sh: -DPDWT_LD_NT=1 gives every streaming load of a translation unit the non-temporal hint)
+#if defined(PDWT_LD_NT) && PDWT_LD_NT
+#define PDWT_LD_POLICY " nt"
+#else
+#define PDWT_LD_POLICY ""
+#endif
 __device__ __forceinline__ void asm_load_s(v4f& d, const float* sbase, unsigned voff)
 {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" PDWT_LD_POLICY : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void asm_load_s(v2f& d, const float* sbase, unsigned voff)
 {
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, %2" PDWT_LD_POLICY : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void asm_load_s(float& d, const float* sbase, unsigned voff)
 {
-    asm volatile("global_load_dword %0, %1, %2" : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("global_load_dword %0, %1, %2" PDWT_LD_POLICY : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void asm_store_sm(float* sbase, unsigned voff, v2f d, lanemask_t mask)
 {
