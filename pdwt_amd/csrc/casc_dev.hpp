@@ -28,9 +28,27 @@ struct CascMap {
     int cpx;     // W == 1: chunk rows per XCD (all 8 XCDs get the same number); W > 1: workgroups per XCD
     int strips;  // strips per chunk row
     int gy;      // W > 1: workgroup-chunk rows (gy * strips workgroups in all)
-    int flags;   // (unused)
+    int flags;   // XCD weighting of the chunk split, see casc_chunk_start (0 = even split)
     const void* tbl;  // batched launch (gridDim.y = images): device array of CascBatchF / CascBatchI, one entry per image; NULL = one image
 };
+// Chunk boundaries of the workgroup-chunk rows of ONE strip, weighted by XCD.  In-kernel timelines (tools/casc_trace.py, three boxes) show
+// the workgroups of the odd XCDs ending 0.7-1.7 us after those of the even ones, in both directions: the same rows take them ~5 % longer.
+// Every strip is split over its cm.gy workgroups independently of the other strips, so a workgroup on an even XCD simply takes `d`
+// units (level-2 rows forward, level-(l+1) row pairs inverse) more than the even split and one on an odd XCD `d` fewer: boundary g of
+// strip s moves by d * (#even - #odd workgroups above it).  cm.flags = d (knob casc_xcdw), 0 = the even split.  Same function on the host
+// (the launchers replay the split to decide whether every wave has a straight-line program).
+__host__ __device__ inline int casc_chunk_start(int g, int strip, int units, int gy, int strips, int cpx, int d)
+{
+    if (g >= gy) return units;
+    int b = (int)(((long long)g * units) / gy);
+    if (d != 0) {
+        int bal = 0;
+        for (int q = 0; q < g; q++) bal += (((q * strips + strip) / cpx) & 1) ? -1 : 1;
+        b += d * bal;
+    }
+    return b;
+}
+
 struct CascBands {
     float *H1, *V1, *D1, *A2, *H2, *V2, *D2;
 };

@@ -131,6 +131,7 @@ enum KnobId {
     KN_CASC_IWG,           // inverse cascade: the same (0 = auto, 1 = independent waves)
     KN_CASC_L3,            // third level folded into the inverse cascade launch: 1 = streamed (dwt_casc_inv3.hip) where it applies, 2 = prologue form only, 0 = never
     KN_CASC_SPEC,          // cascade kernels: straight-line wave programs for the common per-wave row counts (bit 0 forward, bit 1 inverse)
+    KN_CASC_XCDW,          // cascade wave programs: units a workgroup on an even XCD takes more (odd: fewer) than the even split of its strip (0 = even split)
     KN_STREAM,             // 0: LDS-tiled fused level kernels instead of the streaming ones
     KN_STREAM_R,           // streaming level kernels: rows per wave (0 = auto)
     KN_STREAM_WAVES,       // streaming level kernels: target waves per launch

@@ -47,6 +47,63 @@ constexpr int casc_fwd_after(int p)
 template <int HLEN>
 constexpr int casc_fwd_region_bytes() { return (HLEN - 2) * 64 * (16 + 8); }
 
+// The forward column passes of an 8-tap bank as ONE asm statement each (cf. col_synth4x4 in dwt_casc_inv3.hip: between separate statements that
+// depend on each other hipcc inserts a wait state it does not need).  (A, H) += lo * (L[k], H[k]) and (V, D) += hi * (L[k], H[k]) for the
+// two columns of a lane, ring entries r?0 / r?1 = (lo, hi) of column 0 / 1 in window order, taps t0..t7 in window order.
+#define PDWT_VB_F0 " op_sel_hi:[0,1,0]"
+#define PDWT_VB_N0 " op_sel_hi:[0,1,1]"
+#define PDWT_VB_F1 " op_sel:[1,0,0] op_sel_hi:[1,1,0]"
+#define PDWT_VB_N1 " op_sel:[1,0,0]"
+// WITH_VD = false: only the (A, H) sums (rows whose H, V, D the wave does not store: the V, D sums would be dead)
+template <bool WITH_VD>
+__device__ __forceinline__ void col_pass8x2(v2f& ah0, v2f& ah1, v2f& vd0, v2f& vd1, v2f a0, v2f a1, v2f a2, v2f a3, v2f a4, v2f a5, v2f a6, v2f a7, v2f b0, v2f b1,
+                                            v2f b2, v2f b3, v2f b4, v2f b5, v2f b6, v2f b7, v2f t0, v2f t1, v2f t2, v2f t3, v2f t4, v2f t5, v2f t6, v2f t7)
+{
+#define PDWT_CP_ROW(A, B, T, AC)                                                                                              \
+    "v_pk_fma_f32 %0, " A ", " T ", " AC "0\n\tv_pk_fma_f32 %1, " B ", " T ", " AC "1\n\t"
+    if constexpr (WITH_VD) {
+        asm("v_pk_fma_f32 %0, %4, %20, 0" PDWT_VB_F0 "\n\tv_pk_fma_f32 %1, %12, %20, 0" PDWT_VB_F0 "\n\tv_pk_fma_f32 %2, %4, %20, 0" PDWT_VB_F1 "\n\tv_pk_fma_f32 %3, %12, %20, 0" PDWT_VB_F1
+            "\n\tv_pk_fma_f32 %0, %5, %21, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %13, %21, %1" PDWT_VB_N0 "\n\tv_pk_fma_f32 %2, %5, %21, %2" PDWT_VB_N1 "\n\tv_pk_fma_f32 %3, %13, %21, %3" PDWT_VB_N1
+            "\n\tv_pk_fma_f32 %0, %6, %22, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %14, %22, %1" PDWT_VB_N0 "\n\tv_pk_fma_f32 %2, %6, %22, %2" PDWT_VB_N1 "\n\tv_pk_fma_f32 %3, %14, %22, %3" PDWT_VB_N1
+            "\n\tv_pk_fma_f32 %0, %7, %23, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %15, %23, %1" PDWT_VB_N0 "\n\tv_pk_fma_f32 %2, %7, %23, %2" PDWT_VB_N1 "\n\tv_pk_fma_f32 %3, %15, %23, %3" PDWT_VB_N1
+            "\n\tv_pk_fma_f32 %0, %8, %24, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %16, %24, %1" PDWT_VB_N0 "\n\tv_pk_fma_f32 %2, %8, %24, %2" PDWT_VB_N1 "\n\tv_pk_fma_f32 %3, %16, %24, %3" PDWT_VB_N1
+            "\n\tv_pk_fma_f32 %0, %9, %25, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %17, %25, %1" PDWT_VB_N0 "\n\tv_pk_fma_f32 %2, %9, %25, %2" PDWT_VB_N1 "\n\tv_pk_fma_f32 %3, %17, %25, %3" PDWT_VB_N1
+            "\n\tv_pk_fma_f32 %0, %10, %26, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %18, %26, %1" PDWT_VB_N0 "\n\tv_pk_fma_f32 %2, %10, %26, %2" PDWT_VB_N1 "\n\tv_pk_fma_f32 %3, %18, %26, %3" PDWT_VB_N1
+            "\n\tv_pk_fma_f32 %0, %11, %27, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %19, %27, %1" PDWT_VB_N0 "\n\tv_pk_fma_f32 %2, %11, %27, %2" PDWT_VB_N1 "\n\tv_pk_fma_f32 %3, %19, %27, %3" PDWT_VB_N1
+            : "=&v"(ah0), "=&v"(ah1), "=&v"(vd0), "=&v"(vd1)
+            : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4), "v"(b5), "v"(b6), "v"(b7),
+              "s"(t0), "s"(t1), "s"(t2), "s"(t3), "s"(t4), "s"(t5), "s"(t6), "s"(t7));
+    } else {
+        asm("v_pk_fma_f32 %0, %2, %18, 0" PDWT_VB_F0 "\n\tv_pk_fma_f32 %1, %10, %18, 0" PDWT_VB_F0
+            "\n\tv_pk_fma_f32 %0, %3, %19, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %11, %19, %1" PDWT_VB_N0
+            "\n\tv_pk_fma_f32 %0, %4, %20, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %12, %20, %1" PDWT_VB_N0
+            "\n\tv_pk_fma_f32 %0, %5, %21, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %13, %21, %1" PDWT_VB_N0
+            "\n\tv_pk_fma_f32 %0, %6, %22, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %14, %22, %1" PDWT_VB_N0
+            "\n\tv_pk_fma_f32 %0, %7, %23, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %15, %23, %1" PDWT_VB_N0
+            "\n\tv_pk_fma_f32 %0, %8, %24, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %16, %24, %1" PDWT_VB_N0
+            "\n\tv_pk_fma_f32 %0, %9, %25, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %17, %25, %1" PDWT_VB_N0
+            : "=&v"(ah0), "=&v"(ah1)
+            : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4), "v"(b5), "v"(b6), "v"(b7),
+              "s"(t0), "s"(t1), "s"(t2), "s"(t3), "s"(t4), "s"(t5), "s"(t6), "s"(t7));
+    }
+#undef PDWT_CP_ROW
+}
+// the level-2 column pass: one column per lane, (A2, H2) += lo * taps, (V2, D2) += hi * taps
+__device__ __forceinline__ void col_pass8x1(v2f& ah, v2f& vd, v2f a0, v2f a1, v2f a2, v2f a3, v2f a4, v2f a5, v2f a6, v2f a7, v2f t0, v2f t1, v2f t2, v2f t3, v2f t4,
+                                            v2f t5, v2f t6, v2f t7)
+{
+    asm("v_pk_fma_f32 %0, %2, %10, 0" PDWT_VB_F0 "\n\tv_pk_fma_f32 %1, %2, %10, 0" PDWT_VB_F1
+        "\n\tv_pk_fma_f32 %0, %3, %11, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %3, %11, %1" PDWT_VB_N1
+        "\n\tv_pk_fma_f32 %0, %4, %12, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %4, %12, %1" PDWT_VB_N1
+        "\n\tv_pk_fma_f32 %0, %5, %13, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %5, %13, %1" PDWT_VB_N1
+        "\n\tv_pk_fma_f32 %0, %6, %14, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %6, %14, %1" PDWT_VB_N1
+        "\n\tv_pk_fma_f32 %0, %7, %15, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %7, %15, %1" PDWT_VB_N1
+        "\n\tv_pk_fma_f32 %0, %8, %16, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %8, %16, %1" PDWT_VB_N1
+        "\n\tv_pk_fma_f32 %0, %9, %17, %0" PDWT_VB_N0 "\n\tv_pk_fma_f32 %1, %9, %17, %1" PDWT_VB_N1
+        : "=&v"(ah), "=&v"(vd)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "s"(t0), "s"(t1), "s"(t2), "s"(t3), "s"(t4), "s"(t5), "s"(t6), "s"(t7));
+}
+
 // Bookkeeping of a straight-line wave program (see the kernel): R2 level-2 rows, last wave of its workgroup or not, DIST A1 rows
 // of prefetch.  Everything here is a function of the A1 row index alone.
 template <int HLEN, int R2, bool LV, int DIST>
@@ -121,8 +178,8 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
         if (slot >= cm.cpx || wg >= cm.gy * cm.strips) return;  // (uniform over the workgroup: nobody is left at the barrier)
         const int gy = wg / cm.strips;
         strip = wg % cm.strips;
-        const int J0 = (int)(((long long)gy * Nr4) / cm.gy);
-        const int R = (int)(((long long)(gy + 1) * Nr4) / cm.gy) - J0;
+        const int J0 = casc_chunk_start(gy, strip, Nr4, cm.gy, cm.strips, cm.cpx, cm.flags);
+        const int R = casc_chunk_start(gy + 1, strip, Nr4, cm.gy, cm.strips, cm.cpx, cm.flags) - J0;
         // split of the R level-2 rows: the last wave also streams the 3(HLEN-2) halo input rows below the workgroup's
         // chunk (worth E level-2 rows of work), so it gets E rows fewer (at least one is left); the host guarantees
         // R / W >= HLEN / 2 (two barriers in the first super-body order the hand-off, see the loop)
@@ -426,16 +483,25 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                     v2f ah[2], vd[2];
 #pragma unroll
                     for (int p = 0; p < 2; p++) ah[p] = vd[p] = v2f{0.f, 0.f};
-                    static_for<HLEN>([&](auto J) {
-                        constexpr int j = decltype(J)::value;
-                        constexpr int s = (2 * n + j) % HLEN;
-                        const v2f t = f.t[HLEN - 1 - j];
+                    if constexpr (HLEN == 8) {
+                        constexpr int q = (2 * n) % 8;  // ring slot of window position 0
+#define PDWT_R(j, p) ring[(q + (j)) % 8][p]
+                        col_pass8x2<store1>(ah[0], ah[1], vd[0], vd[1], PDWT_R(0, 0), PDWT_R(1, 0), PDWT_R(2, 0), PDWT_R(3, 0), PDWT_R(4, 0), PDWT_R(5, 0), PDWT_R(6, 0),
+                                            PDWT_R(7, 0), PDWT_R(0, 1), PDWT_R(1, 1), PDWT_R(2, 1), PDWT_R(3, 1), PDWT_R(4, 1), PDWT_R(5, 1), PDWT_R(6, 1), PDWT_R(7, 1),
+                                            f.t[7], f.t[6], f.t[5], f.t[4], f.t[3], f.t[2], f.t[1], f.t[0]);
+#undef PDWT_R
+                    } else {
+                        static_for<HLEN>([&](auto J) {
+                            constexpr int j = decltype(J)::value;
+                            constexpr int s = (2 * n + j) % HLEN;
+                            const v2f t = f.t[HLEN - 1 - j];
 #pragma unroll
-                        for (int p = 0; p < 2; p++) {
-                            ah[p] = pk_fma_vbcast<0, j == 0>(ring[s][p], t, ah[p]);
-                            if constexpr (store1) vd[p] = pk_fma_vbcast<1, j == 0>(ring[s][p], t, vd[p]);
-                        }
-                    });
+                            for (int p = 0; p < 2; p++) {
+                                ah[p] = pk_fma_vbcast<0, j == 0>(ring[s][p], t, ah[p]);
+                                if constexpr (store1) vd[p] = pk_fma_vbcast<1, j == 0>(ring[s][p], t, vd[p]);
+                            }
+                        });
+                    }
                     if constexpr (store1) {
                         asm_store3_sm(b.H1, b.V1, b.D1, off1 + s1off, v2f{ah[0].y, ah[1].y}, v2f{vd[0].x, vd[1].x}, v2f{vd[0].y, vd[1].y}, vmask);
                         s1off += (unsigned)Nc2 * 4u;
@@ -450,13 +516,19 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
                 }
                 if constexpr ((n & 1) && n >= HLEN - 1) {
                     v2f ah2 = {0.f, 0.f}, vd2 = {0.f, 0.f};
-                    static_for<HLEN>([&](auto J) {
-                        constexpr int j = decltype(J)::value;
-                        constexpr int s = (a + 1 + j) % HLEN;
-                        const v2f t = f.t[HLEN - 1 - j];
-                        ah2 = pk_fma_vbcast<0, j == 0>(ring2[s], t, ah2);
-                        vd2 = pk_fma_vbcast<1, j == 0>(ring2[s], t, vd2);
-                    });
+                    if constexpr (HLEN == 8) {
+                        constexpr int q = (a + 1) % 8;
+                        col_pass8x1(ah2, vd2, ring2[q], ring2[(q + 1) % 8], ring2[(q + 2) % 8], ring2[(q + 3) % 8], ring2[(q + 4) % 8], ring2[(q + 5) % 8],
+                                    ring2[(q + 6) % 8], ring2[(q + 7) % 8], f.t[7], f.t[6], f.t[5], f.t[4], f.t[3], f.t[2], f.t[1], f.t[0]);
+                    } else {
+                        static_for<HLEN>([&](auto J) {
+                            constexpr int j = decltype(J)::value;
+                            constexpr int s = (a + 1 + j) % HLEN;
+                            const v2f t = f.t[HLEN - 1 - j];
+                            ah2 = pk_fma_vbcast<0, j == 0>(ring2[s], t, ah2);
+                            vd2 = pk_fma_vbcast<1, j == 0>(ring2[s], t, vd2);
+                        });
+                    }
                     asm_store4_sm(b.A2, b.H2, b.V2, b.D2, off2 + s2off, ah2.x, ah2.y, vd2.x, vd2.y, vmask);
                     s2off += (unsigned)Nc4 * 4u;
                 }
@@ -836,8 +908,6 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
         while (gy > 1 && (nr4 / gy) / W < HLEN / 2) gy--;  // every wave needs >= HLEN/2 level-2 rows (see the kernel)
         if (gy >= 1 && (nr4 / gy) / W >= HLEN / 2) {
             const int nwg = gy * strips;
-            const CascMap cm = {idiv_up(nwg, 8), strips, gy, 0, d_tbl};
-            const dim3 grid((unsigned)(8 * cm.cpx), (unsigned)(d_tbl ? nimg : 1));
             const size_t lds = (size_t)(W - 1) * REG;  // hand-off regions
             // (HLEN row registers in flight instead of HLEN/2 measured slower in this form too: 24.8 vs 24.6 us at W = 8)
             void (*k)(const float*, CascBands, int, int, int, float*, CascMap, TapsLH);
@@ -849,12 +919,31 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
             // the straight-line wave programs (kernel form SPEC) exist for waves of 4 or 5 level-2 rows whose workgroup's last wave has 1:
             // the kernel's split, replayed on the two chunk sizes that occur (C2: 73 or 74 level-2 rows over 16 waves)
             bool spec = nv2 && (knob(KN_CASC_SPEC) & 1) && 2 * 4 >= HLEN;
-            for (int R : {nr4 / gy, idiv_up(nr4, gy)}) {
-                const int E = std::min((3 * (HLEN - 2) + 3) / 4, R / 16 - 1);
-                const int base = (R + E) / 16, rem = (R + E) % 16;
-                spec = spec && base == 4 && R - (15 * base + std::min(15, rem)) == 1;
+            // XCD-weighted split (casc_chunk_start): only with the wave programs, and only if every workgroup still has them
+            int xw = spec ? knob(KN_CASC_XCDW) : 0;
+            for (int pass = 0; pass < 2; pass++) {
+                bool ok = spec;
+                for (int g = 0; g < gy && ok; g++)
+                    for (int st = 0; st < strips && ok; st++) {
+                        const int R = casc_chunk_start(g + 1, st, nr4, gy, strips, idiv_up(nwg, 8), xw) - casc_chunk_start(g, st, nr4, gy, strips, idiv_up(nwg, 8), xw);
+                        if (R < 16) {
+                            ok = false;
+                            break;
+                        }
+                        const int E = std::min((3 * (HLEN - 2) + 3) / 4, R / 16 - 1);
+                        const int base = (R + E) / 16, rem = (R + E) % 16;
+                        ok = base == 4 && R - (15 * base + std::min(15, rem)) == 1;
+                    }
+                if (ok || xw == 0) {
+                    spec = ok;
+                    break;
+                }
+                xw = 0;  // the weighted split leaves the instantiated row counts: even split
             }
+            if (!spec) xw = 0;
             if (spec) k = k_fwd2d_casc<HLEN, 2, 16, true>;
+            const CascMap cm = {idiv_up(nwg, 8), strips, gy, xw, d_tbl};
+            const dim3 grid((unsigned)(8 * cm.cpx), (unsigned)(d_tbl ? nimg : 1));
             if (lds > 64 * 1024) {  // opt-in once per (kernel, device), not per launch
                 int rc = (W == 4) ? lds_opt_in<k_fwd2d_casc<HLEN, NVD, 4>>()
                          : (W == 8) ? lds_opt_in<k_fwd2d_casc<HLEN, NVD, 8>>() : lds_opt_in<k_fwd2d_casc<HLEN, NVD, 16>>();

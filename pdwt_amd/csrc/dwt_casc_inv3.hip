@@ -36,6 +36,46 @@ namespace pdwt {
 template <int HLEN>
 constexpr int casc_inv3_region_bytes() { return (HLEN / 2 - 1) * 64 * (16 + 32); }
 
+// Column syntheses of a 4-tap half bank (hlen 8) as ONE asm statement each.  As separate statements (pk_fma_sbcast, one per tap) hipcc puts a
+// wait state between any two that depend on each other -- it cannot see what is inside -- ~100 s_nop per wave of ~1900 instructions in
+// a kernel that is bound by instruction issue.  HALF: which half of the aligned SGPR tap pairs (F[2i], F[2i+1]) is broadcast (tap parity);
+// window position j meets pair 3 - j.  Four independent accumulators interleaved; every scalar still sums its taps in ascending j.
+#define PDWT_PKS_FIRST0 " op_sel_hi:[1,0,0]"
+#define PDWT_PKS_NEXT0 " op_sel_hi:[1,0,1]"
+#define PDWT_PKS_FIRST1 " op_sel:[0,1,0] op_sel_hi:[1,1,0]"
+#define PDWT_PKS_NEXT1 " op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+template <int HALF>
+__device__ __forceinline__ void col_synth4x4(v2f& sa, v2f& sh, v2f& sv, v2f& sd, v2f a0, v2f a1, v2f a2, v2f a3, v2f h0, v2f h1, v2f h2, v2f h3, v2f v0,
+                                             v2f v1, v2f v2, v2f v3, v2f d0, v2f d1, v2f d2, v2f d3, v2f fa3, v2f fa2_, v2f fa1, v2f fa0, v2f fb3, v2f fb2_,
+                                             v2f fb1, v2f fb0)
+{
+#define PDWT_CS4(F, N)                                                                                                                    \
+    asm("v_pk_fma_f32 %0, %4, %20, 0" F "\n\tv_pk_fma_f32 %1, %8, %24, 0" F "\n\tv_pk_fma_f32 %2, %12, %20, 0" F "\n\tv_pk_fma_f32 %3, %16, %24, 0" F \
+        "\n\tv_pk_fma_f32 %0, %5, %21, %0" N "\n\tv_pk_fma_f32 %1, %9, %25, %1" N "\n\tv_pk_fma_f32 %2, %13, %21, %2" N "\n\tv_pk_fma_f32 %3, %17, %25, %3" N \
+        "\n\tv_pk_fma_f32 %0, %6, %22, %0" N "\n\tv_pk_fma_f32 %1, %10, %26, %1" N "\n\tv_pk_fma_f32 %2, %14, %22, %2" N "\n\tv_pk_fma_f32 %3, %18, %26, %3" N \
+        "\n\tv_pk_fma_f32 %0, %7, %23, %0" N "\n\tv_pk_fma_f32 %1, %11, %27, %1" N "\n\tv_pk_fma_f32 %2, %15, %23, %2" N "\n\tv_pk_fma_f32 %3, %19, %27, %3" N \
+        : "=&v"(sa), "=&v"(sh), "=&v"(sv), "=&v"(sd)                                                                                       \
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(d0), "v"(d1), "v"(d2),  \
+          "v"(d3), "s"(fa3), "s"(fa2_), "s"(fa1), "s"(fa0), "s"(fb3), "s"(fb2_), "s"(fb1), "s"(fb0))
+    if constexpr (HALF == 0) PDWT_CS4(PDWT_PKS_FIRST0, PDWT_PKS_NEXT0);
+    else PDWT_CS4(PDWT_PKS_FIRST1, PDWT_PKS_NEXT1);
+#undef PDWT_CS4
+}
+template <int HALF>
+__device__ __forceinline__ void col_synth2x4(v2f& sav, v2f& shd, v2f a0, v2f a1, v2f a2, v2f a3, v2f h0, v2f h1, v2f h2, v2f h3, v2f fa3, v2f fa2_, v2f fa1,
+                                             v2f fa0, v2f fb3, v2f fb2_, v2f fb1, v2f fb0)
+{
+#define PDWT_CS2(F, N)                                                                                                      \
+    asm("v_pk_fma_f32 %0, %2, %10, 0" F "\n\tv_pk_fma_f32 %1, %6, %14, 0" F "\n\tv_pk_fma_f32 %0, %3, %11, %0" N "\n\tv_pk_fma_f32 %1, %7, %15, %1" N \
+        "\n\tv_pk_fma_f32 %0, %4, %12, %0" N "\n\tv_pk_fma_f32 %1, %8, %16, %1" N "\n\tv_pk_fma_f32 %0, %5, %13, %0" N "\n\tv_pk_fma_f32 %1, %9, %17, %1" N \
+        : "=&v"(sav), "=&v"(shd)                                                                                            \
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(h0), "v"(h1), "v"(h2), "v"(h3), "s"(fa3), "s"(fa2_), "s"(fa1), "s"(fa0), "s"(fb3), "s"(fb2_),  \
+          "s"(fb1), "s"(fb0))
+    if constexpr (HALF == 0) PDWT_CS2(PDWT_PKS_FIRST0, PDWT_PKS_NEXT0);
+    else PDWT_CS2(PDWT_PKS_FIRST1, PDWT_PKS_NEXT1);
+#undef PDWT_CS2
+}
+
 // Bookkeeping of a straight-line wave program (see the kernel): NQ level-(l+1) rows, last wave of its workgroup or not.  Everything is a
 // function of the step index s: which parts of a step run, which loads it issues, how many VMEM instructions lie between a load
 // and its use.  Order of the VMEM instructions of a step (the loop's order): [level l+2: wait, 4 loads] [level l+1: wait, NL2 loads]
@@ -98,8 +138,8 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     const int gy = wg / cm.strips, strip = wg % cm.strips;
     // rows are dealt in PAIRS (see PHI): workgroup chunk [J0, J0 + R), wave chunk [Q0, Q0 + nQ), all even
     const int Np = Nr2 >> 1;
-    const int Jp = (int)(((long long)gy * Np) / cm.gy);
-    const int Rp = (int)(((long long)(gy + 1) * Np) / cm.gy) - Jp;
+    const int Jp = casc_chunk_start(gy, strip, Np, cm.gy, cm.strips, cm.cpx, cm.flags);
+    const int Rp = casc_chunk_start(gy + 1, strip, Np, cm.gy, cm.strips, cm.cpx, cm.flags) - Jp;
     // every wave runs nQ + XS steps (the last XS of the last wave are full steps: it recomputes its halo; the others only run the
     // level-l part on rows from the hand-off), so an even split of the pairs is the balanced one (timeline: r03_c2_timeline.md)
     const int Ep = 0;
@@ -203,13 +243,19 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     auto synth_col = [&](const v2f (&av)[H2], const v2f (&hd)[H2], auto S0, auto OFF) {
         constexpr int s0 = decltype(S0)::value, off = decltype(OFF)::value;
         v2f sav = {0.f, 0.f}, shd = {0.f, 0.f};
-        static_for<H2>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            constexpr int sl = (s0 + j) % H2;
-            constexpr int k = HLEN - 1 - (2 * j + off);
-            sav = pk_fma_sbcast<k & 1, j == 0>(av[sl], fa2[k >> 1], sav);
-            shd = pk_fma_sbcast<k & 1, j == 0>(hd[sl], fb2[k >> 1], shd);
-        });
+        if constexpr (H2 == 4) {
+            constexpr int half = (HLEN - 1 - off) & 1;  // (the parity of tap k = HLEN-1-(2j+off) does not depend on j)
+            col_synth2x4<half>(sav, shd, av[s0 % 4], av[(s0 + 1) % 4], av[(s0 + 2) % 4], av[(s0 + 3) % 4], hd[s0 % 4], hd[(s0 + 1) % 4], hd[(s0 + 2) % 4],
+                               hd[(s0 + 3) % 4], fa2[3], fa2[2], fa2[1], fa2[0], fb2[3], fb2[2], fb2[1], fb2[0]);
+        } else {
+            static_for<H2>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                constexpr int sl = (s0 + j) % H2;
+                constexpr int k = HLEN - 1 - (2 * j + off);
+                sav = pk_fma_sbcast<k & 1, j == 0>(av[sl], fa2[k >> 1], sav);
+                shd = pk_fma_sbcast<k & 1, j == 0>(hd[sl], fb2[k >> 1], shd);
+            });
+        }
         const v2f t = sav + shd;  // (t1, t2) of the lane's column
         float t1w[H2], t2w[H2];   // window of p = c: columns c-C .. c-C+H2-1
         t1w[C] = t.x;
@@ -321,15 +367,22 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
         asm("" : "=v"(o4));  // (a row that goes to the trash carries whatever these registers hold: no instruction spent on it)
         if (own) {
             v2f sa = {0.f, 0.f}, sh = {0.f, 0.f}, sv = {0.f, 0.f}, sd = {0.f, 0.f};
-            static_for<H2>([&](auto J) {
-                constexpr int j = decltype(J)::value;
-                constexpr int sl = (s0 + j) % H2;
-                constexpr int k = HLEN - 1 - (2 * j + off);
-                sa = pk_fma_sbcast<k & 1, j == 0>(ra[sl], fa2[k >> 1], sa);
-                sh = pk_fma_sbcast<k & 1, j == 0>(rh[sl], fb2[k >> 1], sh);
-                sv = pk_fma_sbcast<k & 1, j == 0>(rv[sl], fa2[k >> 1], sv);
-                sd = pk_fma_sbcast<k & 1, j == 0>(rd[sl], fb2[k >> 1], sd);
-            });
+            if constexpr (H2 == 4) {
+                constexpr int half = (HLEN - 1 - off) & 1;
+                constexpr int j0 = s0 % 4, j1 = (s0 + 1) % 4, j2 = (s0 + 2) % 4, j3 = (s0 + 3) % 4;
+                col_synth4x4<half>(sa, sh, sv, sd, ra[j0], ra[j1], ra[j2], ra[j3], rh[j0], rh[j1], rh[j2], rh[j3], rv[j0], rv[j1], rv[j2], rv[j3], rd[j0],
+                                   rd[j1], rd[j2], rd[j3], fa2[3], fa2[2], fa2[1], fa2[0], fb2[3], fb2[2], fb2[1], fb2[0]);
+            } else {
+                static_for<H2>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    constexpr int sl = (s0 + j) % H2;
+                    constexpr int k = HLEN - 1 - (2 * j + off);
+                    sa = pk_fma_sbcast<k & 1, j == 0>(ra[sl], fa2[k >> 1], sa);
+                    sh = pk_fma_sbcast<k & 1, j == 0>(rh[sl], fb2[k >> 1], sh);
+                    sv = pk_fma_sbcast<k & 1, j == 0>(rv[sl], fa2[k >> 1], sv);
+                    sd = pk_fma_sbcast<k & 1, j == 0>(rd[sl], fb2[k >> 1], sd);
+                });
+            }
             const v2f t1o = sa + sh, t2o = sv + sd;
             // t columns c0 + 1 - C .. c0 + 2 - C + H2 - 1 (both windows), index 0 = column c0 + 1 - C; the lane's own two sit at C-1, C
             constexpr int NT = H2 + 1;
@@ -730,16 +783,32 @@ static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* o
     }
     if (!W) return 1;
     const int nwg = gy * strips;
-    const CascMap cm = {idiv_up(nwg, 8), strips, gy, 0, d_tbl};
-    const dim3 grid((unsigned)(8 * cm.cpx), (unsigned)(d_tbl ? nimg : 1));
+    
     const size_t lds = lds_bytes(W);
     void (*k)(CascInvBands, CascInv3B, float*, int, int, int, float*, CascMap, Taps2<float>);
     k = (W == 4) ? k_inv2d_casc3<HLEN, 4, L3> : (W == 8) ? k_inv2d_casc3<HLEN, 8, L3> : (W == 12) ? k_inv2d_casc3<HLEN, 12, L3> : k_inv2d_casc3<HLEN, 16, L3>;
     // the straight-line wave programs (kernel form SPEC) exist for waves of 4 or 6 level-(l+1) rows whose workgroup's last wave has 4:
     // the kernel's split, replayed on the two chunk sizes that occur (C2: 36 or 37 row pairs over 16 waves)
     bool spec = W == 16 && ((knob(KN_CASC_SPEC) >> 1) & 1) && H2 <= 4;
-    for (int Rp : {np / gy, idiv_up(np, gy)}) spec = spec && (Rp / 16 == 2);
+    // XCD-weighted split (casc_chunk_start): only with the wave programs, and only if every workgroup still has them
+    int xw = spec ? knob(KN_CASC_XCDW) : 0;
+    for (int pass = 0; pass < 2; pass++) {
+        bool ok = spec;
+        for (int g = 0; g < gy && ok; g++)
+            for (int st = 0; st < strips && ok; st++) {
+                const int Rp = casc_chunk_start(g + 1, st, np, gy, strips, idiv_up(nwg, 8), xw) - casc_chunk_start(g, st, np, gy, strips, idiv_up(nwg, 8), xw);
+                ok = Rp / 16 == 2;
+            }
+        if (ok || xw == 0) {
+            spec = ok;
+            break;
+        }
+        xw = 0;
+    }
+    if (!spec) xw = 0;
     if (spec) k = k_inv2d_casc3<HLEN, 16, L3, true>;
+    const CascMap cm = {idiv_up(nwg, 8), strips, gy, xw, d_tbl};
+    const dim3 grid((unsigned)(8 * cm.cpx), (unsigned)(d_tbl ? nimg : 1));
     if (lds > 64 * 1024) {  // opt-in once per (kernel, device), not per launch
         const int rc = spec ? lds_opt_in<k_inv2d_casc3<HLEN, 16, L3, true>>()
                        : (W == 4) ? lds_opt_in<k_inv2d_casc3<HLEN, 4, L3>>() : (W == 8) ? lds_opt_in<k_inv2d_casc3<HLEN, 8, L3>>() : (W == 12) ? lds_opt_in<k_inv2d_casc3<HLEN, 12, L3>>() : lds_opt_in<k_inv2d_casc3<HLEN, 16, L3>>();

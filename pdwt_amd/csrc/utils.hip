@@ -222,13 +222,21 @@ __global__ __launch_bounds__(kUThreads) void k_soft_thresh_sum(BandTable<T> tab,
     }
 }
 
+// A pure read stream: every block owns ONE contiguous run of chunks (the walk that streams best on this chip, profiles/r04_hbm_ceiling.md:
+// 6.2 TB/s against 5.0-5.6 for a grid-stride walk), walks it from its END (the pass that wrote the bands -- a threshold, a forward
+// level -- ran front to back, so the tail is what is still in the Infinity Cache), loads non-temporally (7.0 TB/s read-only with the
+// hint; nothing here is read twice) and issues all loads of a chunk before the first use.  Fixed assignment and order: deterministic.
 template <typename T, bool VEC>
 __global__ __launch_bounds__(kUThreads) void k_abs_sum(BandTable<T> tab, double* __restrict__ partial)
 {
     __shared__ double s_w[kUThreads / 64];
     double acc = 0.0;
     const unsigned int total = tab.chunk0[tab.nb];
-    for (unsigned int chunk = blockIdx.x; chunk < total; chunk += gridDim.x) {
+    const unsigned int per = (total + gridDim.x - 1) / gridDim.x;
+    // block b <-> chunks [total - (b+1)*per, total - b*per): block 0 starts with the very last chunk
+    const long long hi = (long long)total - (long long)blockIdx.x * per, lo = hi - per > 0 ? hi - per : 0;
+    for (long long cc = hi - 1; cc >= lo; cc--) {
+        const unsigned int chunk = (unsigned int)cc;
         const int k = find_band(tab.chunk0, tab.nb, chunk);
         const T* __restrict__ p = tab.ptr[k];
         const unsigned long long n = tab.n[k];
@@ -237,16 +245,30 @@ __global__ __launch_bounds__(kUThreads) void k_abs_sum(BandTable<T> tab, double*
         if constexpr (VEC) {
             using V = typename V16<T>::type;
             constexpr int NV = V16<T>::N;
+            constexpr int U = kChunk / (kUThreads * NV);
+            if (base + kChunk <= n) {  // full chunk: no bounds checks, every load in flight before the first use
+                typedef T NTV __attribute__((ext_vector_type(NV)));  // (the builtin wants a native vector type)
+                NTV v[U];
 #pragma unroll
-            for (int u = 0; u < kChunk / (kUThreads * NV); u++) {
-                const unsigned long long i = base + ((unsigned long long)u * kUThreads + threadIdx.x) * NV;
-                if (i + NV <= n) {
-                    const V v = *reinterpret_cast<const V*>(p + i);
-                    const T* e = reinterpret_cast<const T*>(&v);
+                for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(reinterpret_cast<const NTV*>(p + base + ((unsigned long long)u * kUThreads + threadIdx.x) * NV));
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const T* e = reinterpret_cast<const T*>(&v[u]);
 #pragma unroll
                     for (int q = 0; q < NV; q++) acc += sq ? (double)e[q] * (double)e[q] : (double)(e[q] < 0 ? -e[q] : e[q]);
-                } else {
-                    for (unsigned long long j = i; j < n; j++) acc += sq ? (double)p[j] * (double)p[j] : (double)(p[j] < 0 ? -p[j] : p[j]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const unsigned long long i = base + ((unsigned long long)u * kUThreads + threadIdx.x) * NV;
+                    if (i + NV <= n) {
+                        const V v = *reinterpret_cast<const V*>(p + i);
+                        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+                        for (int q = 0; q < NV; q++) acc += sq ? (double)e[q] * (double)e[q] : (double)(e[q] < 0 ? -e[q] : e[q]);
+                    } else {
+                        for (unsigned long long j = i; j < n; j++) acc += sq ? (double)p[j] * (double)p[j] : (double)(p[j] < 0 ? -p[j] : p[j]);
+                    }
                 }
             }
         } else {
