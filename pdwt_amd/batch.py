@@ -78,10 +78,35 @@ class ShardedBatch:
         return [float(o.item()) for o in outs]
 
     def gather_image(self, dst=0):
-        """All shards' reconstructed rows stacked in rank order on rank `dst` (None elsewhere)."""
-        local = self.W.get_image()
+        """All shards' reconstructed rows stacked in rank order on rank `dst` (None elsewhere).
+
+        A tensor gather, not a pickled object: over "nccl" (= RCCL over xGMI) the rows travel GPU to GPU from the engine's device
+        buffer (zero-copy view) and only rank `dst` copies the stacked batch to the host; over "gloo" they travel as host tensors.
+        Shards of different heights are padded to the tallest one for the collective (the counts come from an all-gather of one int)."""
+        import torch
         if not self.collective:
-            return local
-        out = [None] * self.world if self.rank == dst else None
-        self.dist.gather_object(local, out, dst=dst, group=self.group)
-        return np.concatenate(out, axis=0) if self.rank == dst else None
+            return self.W.get_image()
+        nccl = self.dist.get_backend(self.group) == "nccl"
+        dev = "cuda" if nccl else "cpu"
+        if nccl and hasattr(self.W, "image_view"):
+            self.W.sync()
+            local = torch.as_tensor(self.W.image_view(), device="cuda")
+        else:
+            local = torch.from_numpy(np.ascontiguousarray(self.W.get_image())).to(dev)
+        if local.dim() == 1:
+            local = local.reshape(1, -1)
+        rows = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+        counts = [torch.zeros_like(rows) for _ in range(self.world)]
+        self.dist.all_gather(counts, rows, group=self.group)
+        counts = [int(c.item()) for c in counts]
+        hmax = max(counts)
+        if local.shape[0] < hmax:  # pad to the tallest shard (at most one row more than any other: shard_rows)
+            local = torch.cat([local, local.new_zeros((hmax - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
+        local = local.contiguous()
+        dst_global = self.dist.get_global_rank(self.group, dst) if self.group is not None else dst
+        if self.rank == dst:
+            parts = [torch.empty_like(local) for _ in range(self.world)]
+            self.dist.gather(local, parts, dst=dst_global, group=self.group)
+            return np.concatenate([p[:c].cpu().numpy() for p, c in zip(parts, counts)], axis=0)
+        self.dist.gather(local, None, dst=dst_global, group=self.group)
+        return None

@@ -184,3 +184,81 @@ def test_one_process_batch_split_cpp(exe, shards):
     import subprocess
     r = subprocess.run([os.path.join(ROOT, "pdwt_amd", "lib", exe), "37", "2048", "sym8", "4", str(shards)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "batch OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.timeout(900)
+def test_full_c4_batch_eight_shards_on_one_device():
+    """BASELINE configs[3] at its FULL size through the one-process batch split: 65536 signals x 8192 samples, sym8, 4 levels, eight
+    shards (`WaveletsBatch`, devices = {0 x 8}: the split of the 8-GPU node replayed on the one GPU of the test box, 8 x ~1 GiB of
+    device memory).  batch_demo checks the sharded reconstruction against the unsharded instance bit for bit (all 2^29 samples),
+    norm1 before and after the threshold (sum of the per-shard doubles) and that the threshold shrinks it -- the first 8-GPU run is
+    then not the first 8-shard run."""
+    import subprocess
+    r = subprocess.run([os.path.join(ROOT, "pdwt_amd", "lib", "batch_demo"), "65536", "8192", "sym8", "4", "8"], capture_output=True, text=True, timeout=880)
+    assert r.returncode == 0 and "batch OK" in r.stdout and "shards 8" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.timeout(900)
+def test_bench_eight_ranks_c4_code_path_on_one_gpu():
+    """bench.py --config c4 --gpus 8 as the driver launches the scaling run (torch.distributed.run, one process per rank), with the two
+    hooks that let it run on a 1-GPU box (all ranks on device 0, gloo instead of RCCL): every rank asserts its block of the
+    65536-row batch -- shard_rows(8 * 8192, 8, rank) == (rank * 8192, 8192) -- builds its ShardedBatch, the eight ranks all-reduce norm1
+    and rank 0 prints ONE line with n_gpus = 8."""
+    import json
+    import subprocess
+    env = dict(os.environ, PDWT_BENCH_ONE_GPU="1", PDWT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--config", "c4", "--gpus", "8", "--steps", "10", "--warmup", "3",
+                        "--cpu-seconds", "0", "--settle-ms", "20", "--no-roofline"], capture_output=True, text=True, timeout=880, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["sanity"]["norm1_ranks"] == 8 and d["sanity"]["norm1_allreduce_rel_err"] <= 1e-12 and d["roundtrip_max_rel_err"] <= 1e-5
+
+
+def _worker_gather(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    import pdwt_amd
+    from pdwt_amd.batch import ShardedBatch, shard_rows
+    torch.cuda.set_device(0)
+    assert pdwt_amd.hip().pdwt_set_device(0) == 0
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator(device="cuda")
+        g.manual_seed(7)
+        full = torch.randn(4099, 8192, device="cuda", generator=g)  # every rank generates the same batch and keeps its block (uneven split)
+        s, n = shard_rows(full.shape[0], world, rank)
+        B = ShardedBatch(full[s:s + n].contiguous(), "sym8", 4, ndim=1)
+        B.forward()
+        B.inverse()
+        img = B.gather_image(0)  # ~128 MiB as tensors (not a pickled object)
+        if rank == 0:
+            ref = full.cpu().numpy()
+            q.put((img.shape, float(np.abs(img - ref).max() / np.abs(ref).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_gather_image_is_a_tensor_gather_of_large_uneven_shards():
+    """ShardedBatch.gather_image moves the shards as tensors (padded to the tallest shard), not as pickled objects: 4 ranks, 4099 rows of
+    8192 samples (1025 + 1025 + 1025 + 1024), the stacked round trip reproduces the batch."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_gather, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    shape, err = q.get(timeout=500)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert tuple(shape) == (4099, 8192) and err <= 1e-5
