@@ -37,6 +37,7 @@ int main(int argc, char** argv)
     B.forward();
     W.forward();
     const double nb = B.norm1(), nw = (double)W.norm1();
+    const bool rccl = B.last_norm1_used_rccl();  // one shard per device and RCCL loadable: the per-device doubles were all-reduced over RCCL
     B.soft_threshold((DTYPE)0.05);
     W.soft_threshold((DTYPE)0.05);
     const double nbt = B.norm1(), nwt = (double)W.norm1();
@@ -48,8 +49,8 @@ int main(int argc, char** argv)
     size_t diff = 0;
     for (size_t i = 0; i < img.size(); i++) diff += (rb[i] != rw[i]);
     const double tol = sizeof(DTYPE) == 4 ? 2e-6 : 1e-12;
-    printf("shards %d on %d device(s): norm1 %.9e / %.9e, after threshold %.9e / %.9e, %zu differing samples of %zu\n", nshards, ndev, nb, nw,
-           nbt, nwt, diff, got);
+    printf("shards %d on %d device(s): norm1 %.9e / %.9e, after threshold %.9e / %.9e, %zu differing samples of %zu; norm1 exchange: %s\n", nshards, ndev, nb, nw,
+           nbt, nwt, diff, got, rccl ? "RCCL all-reduce" : "host sum");
     const bool ok = got == img.size() && diff == 0 && fabs(nb - nw) <= tol * nw && fabs(nbt - nwt) <= tol * nwt && nbt < nb;
     puts(ok ? "batch OK" : "batch MISMATCH");
     return ok ? 0 : 1;

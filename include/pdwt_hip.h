@@ -38,6 +38,7 @@ extern "C" {
 #define PDWT_EUNKNOWN (-2) /* unknown wavelet name (same value as src/separable.cu:42-45) */
 #define PDWT_EHIP (-3)     /* a HIP runtime call failed (see pdwt_last_error_string) */
 #define PDWT_ENOMEM (-4)
+#define PDWT_ENOTSUP (-5)  /* the optional facility is not available here (RCCL cannot be loaded, a device list it cannot take): use the fallback */
 
 /* == reference `struct w_info`, src/utils.h:9-19 (same field order, 6 x int32) */
 typedef struct pdwt_info {
@@ -121,6 +122,17 @@ void pdwt_batch2d_destroy(void* batch);
  * launch records the shader-clock counter and the 100 MHz real-time counter at its start and end.  slot = direction * 8 + size
  * class (forward 0, inverse 8; class 0 = 16384 rows, 1 = 8192, 2 = 4096, ...): the last launch of that kind.  shader_mhz = the
  * clock the workgroup actually ran at, span_us its lifetime; 0 when nothing was recorded.  Synchronises the stream. */
+/* The one exchange step of the batch split driven from ONE host process (include/wt_batch.h): all-reduce(SUM) of one double per device
+ * over RCCL (xGMI).  in[i] / out[i] are device pointers on devices[i] (distinct devices; may alias); the reduction is enqueued on every
+ * device's library stream and the sum is returned in *result.  RCCL is loaded at run time: pdwt_rccl_available() says whether it could
+ * be; PDWT_ENOTSUP = not here / device list not usable -> add the per-device doubles on the host.  (One process per GPU: pdwt_amd/batch.py
+ * does the same all-reduce through torch.distributed, backend "nccl" = RCCL.)  Reference: none (single-GPU, TODO.txt:15). */
+int pdwt_rccl_available(void);
+int pdwt_rccl_allreduce_sum_f64(int n, const int* devices, const double* const* in, double* const* out, double* result);
+/* the double the reductions above work on: element pdwt_sum_result_index() of a scratch buffer holds the result of
+ * pdwt_norm1_enqueue_* / the one-pass threshold; pdwt_sum_spare_index() is a free double behind it (all-reduce output) */
+size_t pdwt_sum_result_index(void);
+size_t pdwt_sum_spare_index(void);
 /* Bandwidth probe (measurement only, bench.py roofline.copy_ceiling): one launch on the library stream that copies `bytes` from src to dst
  * (mode 0), only reads src (1; dst needs 16 valid bytes) or only writes dst (2) with 16-byte accesses, eight in flight per lane, one
  * contiguous chunk per workgroup.  Time it with pdwt_event_*. */

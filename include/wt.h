@@ -117,6 +117,10 @@ class Wavelets {
      * reduction before it reads the first one and adds the doubles. */
     void norm1_begin();
     double norm1_end();
+    /* ADDITION: device address of the instance's reduction scratch (allocated on first use; pdwt_sum_scratch_doubles() doubles on the
+     * instance's device): after norm1_begin() the double at element pdwt_sum_result_index() is this instance's sum|c| -- what
+     * wt_batch.h hands to the RCCL all-reduce across the devices of a batch.  0 on failure. */
+    intptr_t norm1_scratch_int_ptr(void);
     /* ADDITION: 1 once set_filters_forward() / set_filters_inverse() has replaced the bank of `wname` (wt_batch.h: a batch whose
      * members do not all run the named bank any more is transformed image by image) */
     int custom_filters() const;

@@ -36,7 +36,7 @@ class WaveletsBatch {
 
     /* batched 1-D: `img` is an Nr x Nc host array of Nr signals; devices = device index of every shard (repeats allowed) */
     WaveletsBatch(DTYPE* img, int Nr_, int Nc_, const char* wname, int levels, const std::vector<int>& devices, int do_swt = 0)
-        : Nr(Nr_), Nc(Nc_)
+        : Nr(Nr_), Nc(Nc_), used_rccl_(false), devs_(devices)
     {
         const int n = (int)devices.size();
         const int prev = w_get_device();
@@ -81,11 +81,23 @@ class WaveletsBatch {
     {
         for (size_t s = 0; s < shard.size(); s++)
             if (shard[s]) shard[s]->norm1_begin();
+        /* one shard per device (the deployment this class exists for): the per-device doubles are all-reduced over RCCL (xGMI), grouped,
+         * on the devices' streams -- every device then holds the batch norm, one of them hands it to the host.  Anything else (several
+         * shards on one device, RCCL not loadable): the doubles are added here. */
+        double sum = 0.0;
+        if (rccl_norm1(&sum)) {
+            for (size_t s = 0; s < shard.size(); s++)
+                if (shard[s]) (void)shard[s]->norm1_end(); /* (drains each shard's own reduction; its per-shard value stays intact) */
+            used_rccl_ = true;
+            return sum;
+        }
+        used_rccl_ = false;
         double acc = 0.0;
         for (size_t s = 0; s < shard.size(); s++)
             if (shard[s]) acc += shard[s]->norm1_end();
         return acc;
     }
+    bool last_norm1_used_rccl() const { return used_rccl_; }
     /* the reconstructed batch, shards stacked in order; returns the element count */
     size_t get_image(DTYPE* out)
     {
@@ -96,6 +108,27 @@ class WaveletsBatch {
     }
 
   private:
+    bool used_rccl_;
+    std::vector<int> devs_;
+    bool rccl_norm1(double* out)
+    {
+        if (!pdwt_rccl_available() || shard.empty() || devs_.size() != shard.size()) return false;
+        std::vector<int> dv;
+        std::vector<const double*> in;
+        std::vector<double*> o;
+        const size_t ri = pdwt_sum_result_index(), si = pdwt_sum_spare_index();
+        for (size_t s = 0; s < shard.size(); s++) {
+            if (!shard[s]) return false; /* (an empty shard has no device buffer to contribute: host sum) */
+            for (size_t t = 0; t < dv.size(); t++)
+                if (dv[t] == devs_[s]) return false;
+            double* sc = (double*)shard[s]->norm1_scratch_int_ptr();
+            if (!sc) return false;
+            dv.push_back(devs_[s]);
+            in.push_back(sc + ri);
+            o.push_back(sc + si); /* a spare double of the same buffer: the shard's own sum stays where norm1_end() reads it */
+        }
+        return pdwt_rccl_allreduce_sum_f64((int)dv.size(), dv.data(), in.data(), o.data(), out) == 0;
+    }
     WaveletsBatch(const WaveletsBatch&);
     WaveletsBatch& operator=(const WaveletsBatch&);
 };

@@ -209,8 +209,6 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
 
     const float* const lbase = in + xo;
     auto rowptr = [&](int r) { return lbase + (size_t)wrap1(yb + r, Nr) * Nc; };
-    // steady state: uniform row base on the scalar unit + loop-invariant per-lane byte offset (stream_dev.hpp)
-    auto rowbase = [&](int r) { return in + (size_t)wrap1(yb + r, Nr) * Nc; };
     const unsigned xoff = (unsigned)xo * 4u;
 
     // hand-off area: region kw is READ by this wave (written by wave kw+1), region kw-1 is WRITTEN by it

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
                                                          float* __restrict__ trash, CascMap cm, Taps2<float> f)
 {
     using G = CascInvGeom<HLEN>;
-    constexpr int H2 = G::H2, C = G::C, SHIFT = G::SHIFT, NB1 = G::NB1, NB2 = G::NB2, NBT = G::NBT, WIN1 = G::WIN1, WIN2 = G::WIN2;
+    constexpr int H2 = G::H2, C = G::C, SHIFT = G::SHIFT, NBT = G::NBT;
     static_assert(H2 % 2 == 0, "the parity of a step must be a compile-time constant of the unrolled super-body");
     constexpr int XS = H2 / 2;   // extra (level-l only) steps that drain the last H2-1 level-l windows
     constexpr int PHI = SHIFT;   // chunks start at even level-(l+1) rows: stream row s2 is output (s2 + PHI) & 1 of level-(l+2) step (s2 + PHI) >> 1
@@ -750,7 +750,7 @@ static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* o
                             const CascBatchI* d_tbl, int nimg)
 {
     using G = CascInvGeom<HLEN>;
-    constexpr int H2 = G::H2, XS = H2 / 2;
+    constexpr int H2 = G::H2;
     const int nc1 = nc / 2, np = nr / 8;  // level-(l+1) row PAIRS
     const int strips = idiv_up(nc1, G::MAXVL * 2);
     const int VL = idiv_up(nc1 / 2, strips);

@@ -690,6 +690,8 @@ using namespace pdwt;
 
 extern "C" {
 size_t pdwt_sum_scratch_doubles(void) { return (size_t)kMaxBlocks + 8; }
+size_t pdwt_sum_result_index(void) { return (size_t)kMaxBlocks; }
+size_t pdwt_sum_spare_index(void) { return (size_t)kMaxBlocks + 2; }
 int pdwt_sum_scratch_read(const double* scratch, double* out)
 {
     if (!scratch || !out) return PDWT_EINVAL;

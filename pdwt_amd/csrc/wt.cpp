@@ -439,6 +439,14 @@ static bool norm_in_threshold(const wstate_t* st)
 
 int Wavelets::custom_filters() const { return filters_ ? WS(filters_)->custom : 0; }
 
+intptr_t Wavelets::norm1_scratch_int_ptr(void)
+{
+    ON_MY_DEVICE();
+    if (state == W_CREATION_ERROR) return 0;
+    wstate_t* st = WS(filters_);
+    return (st && sum_scratch(st)) ? (intptr_t)st->d_sum : 0;
+}
+
 void Wavelets::set_norm_cache(int on)
 {
     if (!filters_) return;

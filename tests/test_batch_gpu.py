@@ -177,13 +177,22 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     assert d["sanity"]["norm1_ranks"] == 2 and d["sanity"]["norm1_allreduce_rel_err"] <= 1e-12 and d["roundtrip_max_rel_err"] <= 1e-5
 
 
-@pytest.mark.parametrize("exe,shards", [("batch_demo", 3), ("batch_demod", 2), ("batch_demo", 8)])
+@pytest.mark.parametrize("exe,shards", [("batch_demo", 3), ("batch_demod", 2), ("batch_demo", 8), ("batch_demo", 1), ("batch_demod", 1)])
 def test_one_process_batch_split_cpp(exe, shards):
     """include/wt_batch.h: the batch split driven from ONE host process through the C++ class (an instance per shard on
     device s % ndev, every method switches to its instance's device) equals the unsharded run."""
     import subprocess
     r = subprocess.run([os.path.join(ROOT, "pdwt_amd", "lib", exe), "37", "2048", "sym8", "4", str(shards)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "batch OK" in r.stdout, r.stdout + r.stderr
+    # the norm1 exchange: one shard per device -> the per-device doubles go through RCCL (pdwt_rccl_allreduce_sum_f64: librccl loaded at run
+    # time, ncclCommInitAll + one grouped ncclAllReduce on the library streams; with one visible GPU that is a one-rank communicator -- the
+    # load / init / enqueue / read-back path of the 8-GPU node); several shards on one device -> host sum
+    import pdwt_amd
+    ndev = pdwt_amd.hip().pdwt_device_count()
+    if shards <= ndev and pdwt_amd.hip().pdwt_rccl_available():
+        assert "norm1 exchange: RCCL all-reduce" in r.stdout, r.stdout
+    elif shards > ndev:
+        assert "norm1 exchange: host sum" in r.stdout, r.stdout
 
 
 @pytest.mark.timeout(900)
