@@ -40,7 +40,7 @@ PLAIN_SYMBOLS = ["pdwt_device_count", "pdwt_set_device", "pdwt_get_device", "pdw
                  "pdwt_last_error_string", "pdwt_event_create", "pdwt_event_record", "pdwt_event_sync", "pdwt_event_elapsed_ms",
                  "pdwt_event_destroy", "pdwt_ktime_enable", "pdwt_ktime_reset", "pdwt_ktime_read", "pdwt_kernel_name",
                  "pdwt_kernel_count", "pdwt_graph_allowed", "pdwt_graph_capture_begin", "pdwt_graph_capture_end", "pdwt_graph_launch",
-                 "pdwt_graph_destroy", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set", "pdwt_debug_get", "pdwt_clock_probe_enable", "pdwt_clock_probe_read", "pdwt_clock_probe_dump", "pdwt_probe_bandwidth", "pdwt_rccl_available", "pdwt_rccl_allreduce_sum_f64", "pdwt_sum_result_index", "pdwt_sum_spare_index",
+                 "pdwt_graph_destroy", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set", "pdwt_debug_get", "pdwt_clock_probe_enable", "pdwt_clock_probe_read", "pdwt_clock_probe_dump", "pdwt_probe_bandwidth", "pdwt_selfcheck_vmcnt_order", "pdwt_rccl_available", "pdwt_rccl_allreduce_sum_f64", "pdwt_sum_result_index", "pdwt_sum_spare_index",
                  "pdwt_batch2d_create_f32", "pdwt_batch2d_forward_f32", "pdwt_batch2d_inverse_f32", "pdwt_batch2d_destroy",
                  "pdwt_sum_scratch_doubles", "pdwt_sum_scratch_read"]
 TYPED_SYMBOLS = (["compute_filters_separable", "create_coeffs_buffer", "free_coeffs_buffer", "copy_coeffs_buffer",
@@ -80,6 +80,7 @@ def hip():
     for n in ("pdwt_event_record", "pdwt_event_sync", "pdwt_event_destroy"):
         getattr(L, n).argtypes = [vp]
     L.pdwt_probe_bandwidth.argtypes = [vp, vp, C.c_size_t, ci]
+    L.pdwt_selfcheck_vmcnt_order.restype = C.c_longlong
     L.pdwt_event_elapsed_ms.restype = C.c_float
     L.pdwt_event_elapsed_ms.argtypes = [vp, vp]
     L.pdwt_ktime_read.argtypes = [ci, C.POINTER(ci), C.POINTER(C.c_double)]

@@ -7,6 +7,12 @@
 
 #include "common.hpp"
 
+// The hand-counted memory pipelines below (and the EXEC = 0 stores counted in them) are validated on gfx950 only -- tools/probes/vmcnt_order.hip,
+// pdwt_selfcheck_vmcnt_order() -- and the kernels are scheduled for CDNA4's issue rules: any other target is a build error, not a silent port.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "pdwt_amd streaming kernels: gfx950 (MI355X) only -- see stream_dev.hpp"
+#endif
+
 namespace pdwt {
 
 // bound_ctrl:1 + no `old` operand: the lane without a source reads 0 and the compiler needs no
