@@ -67,7 +67,10 @@ def main():
         sys.exit("no kernel matches %r; kernels: %s" % (pat, ", ".join(n for _, n in starts)))
     for pos, name in found:
         body = txt[pos:]
-        body = body[:body.index("s_endpgm")]
+        # the kernel text ends at its .Lfunc_end label (a kernel may hold several s_endpgm: the wave programs of the cascade kernels each
+        # end the program themselves)
+        m = re.search(r"^\.Lfunc_end\d+:", body, re.M)
+        body = body[:m.start()] if m else body[:body.index("s_endpgm")]
         meta = txt[pos:]
         res = {}
         for key in ("NumSgprs", "NumVgprs", "ScratchSize", "Occupancy", "sgpr_spill_count", "vgpr_spill_count"):
