@@ -145,10 +145,12 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_fwd2d_casc(const floa
     CASC_TRACE_DECL;
     CASC_TRACE(0);
     if constexpr (W > 1) {
-        if (cm.tbl) {  // batched launch: this workgroup's image (uniform -> scalar loads)
-            const CascBatchF e = static_cast<const CascBatchF*>(cm.tbl)[blockIdx.y];
-            in = e.in;
-            b = e.b;
+        if (cm.tbl) {  // batched launch: this workgroup's image -- read through the constant address space: scalar loads, pointers in SGPRs
+            static_assert(sizeof(CascBatchF) == 8 * sizeof(void*), "eight pointers per image");
+            typedef const unsigned long long __attribute__((address_space(4))) * tbl_t;
+            const tbl_t q = (tbl_t)(const unsigned long long*)cm.tbl + 8 * (size_t)blockIdx.y;
+            in = (const float*)q[0];
+            b = CascBands{(float*)q[1], (float*)q[2], (float*)q[3], (float*)q[4], (float*)q[5], (float*)q[6], (float*)q[7]};
         }
     }
     const int lane = threadIdx.x & 63;

@@ -123,11 +123,13 @@ __global__ __launch_bounds__(64 * W) void k_inv2d_casc3(CascInvBands b, CascInv3
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     CASC_TRACE_DECL;
     CASC_TRACE(0);
-    if (cm.tbl) {  // batched launch: this workgroup's image (uniform -> scalar loads)
-        const CascBatchI e = static_cast<const CascBatchI*>(cm.tbl)[blockIdx.y];
-        b = e.b;
-        b3 = e.b3;
-        out = e.out;
+    if (cm.tbl) {  // batched launch: this workgroup's image -- read through the constant address space: scalar loads, pointers in SGPRs
+        static_assert(sizeof(CascBatchI) == 12 * sizeof(void*), "twelve pointers per image");
+        typedef const unsigned long long __attribute__((address_space(4))) * tbl_t;
+        const tbl_t q = (tbl_t)(const unsigned long long*)cm.tbl + 12 * (size_t)blockIdx.y;
+        b = CascInvBands{(const float*)q[0], (const float*)q[1], (const float*)q[2], (const float*)q[3], (const float*)q[4], (const float*)q[5], (const float*)q[6]};
+        b3 = CascInv3B{(const float*)q[7], (const float*)q[8], (const float*)q[9], (const float*)q[10]};
+        out = (float*)q[11];
     }
     const int lane = threadIdx.x & 63;
     const int kw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
