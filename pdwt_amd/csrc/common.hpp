@@ -132,6 +132,7 @@ enum KnobId {
     KN_CASC_L3,            // third level folded into the inverse cascade launch: 1 = streamed (dwt_casc_inv3.hip) where it applies, 2 = prologue form only, 0 = never
     KN_CASC_SPEC,          // cascade kernels: straight-line wave programs for the common per-wave row counts (bit 0 forward, bit 1 inverse)
     KN_CASC_XCDW,          // cascade wave programs: units a workgroup on an even XCD takes more (odd: fewer) than the even split of its strip (0 = even split)
+    KN_DWT1D_LDS_KB,       // batched 1-D, all levels in one launch: largest LDS footprint (KB) of a row's buffers the fused kernels take
     KN_STREAM,             // 0: LDS-tiled fused level kernels instead of the streaming ones
     KN_STREAM_R,           // streaming level kernels: rows per wave (0 = auto)
     KN_STREAM_WAVES,       // streaming level kernels: target waves per launch

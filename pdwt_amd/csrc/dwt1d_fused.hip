@@ -515,7 +515,11 @@ static int set_lds(K kernel, size_t bytes)
     return PDWT_OK;
 }
 
-constexpr size_t kLdsBudget1D = 80 * 1024;  // keep >= 2 workgroups per CU
+// Rows whose buffers need up to 80 KB leave room for two workgroups per CU.  Longer rows (double precision at 8192 samples: 99 KB forward) go to
+// the per-level kernels: with ONE 4-wave workgroup per CU these kernels are slower than the 3.75x traffic they save (tools/dwt1d_budget.py,
+// knob dwt1d_lds_kb = 158: 8192 x 8192 float64 sym8 L4 1.03 ms against 0.85 per level, db20 L3 1.78 against 1.00; float32 rows of 16K / 32K
+// samples 0.525 / 0.500 against 0.543 / 0.505 -- a wash)
+static size_t lds_budget_1d() { return (size_t)knob(KN_DWT1D_LDS_KB) * 1024; }
 
 template <typename T, int HLEN>
 static int launch_fwd(const T* in, T** c, const pdwt_info& w, const Taps2<T>& f)
@@ -525,7 +529,7 @@ static int launch_fwd(const T* in, T** c, const pdwt_info& w, const Taps2<T>& f)
     using G = Fwd1DGeom<T, HLEN>;
     // a single level never writes the second buffer (its approximation goes straight to HBM)
     const size_t lds = ((size_t)G::buf_elems(w.Nc) + (w.nlevels > 1 ? (size_t)G::buf_elems(b.n[1]) : 0)) * sizeof(T);
-    if (lds > kLdsBudget1D) return 1;
+    if (lds > lds_budget_1d()) return 1;
     constexpr int NVh = Vec16<T>::N;
     const bool pre = (w.Nc % NVh) == 0 && ((uintptr_t)in & 15) == 0 && (w.Nc / NVh) <= kPre1D * 256;
     auto k = pre ? k_fwd1d_fused<T, HLEN, true> : k_fwd1d_fused<T, HLEN, false>;
@@ -547,7 +551,7 @@ static int launch_inv(T* out, T** c, const pdwt_info& w, const Taps2<T>& f)
     using G = Inv1DGeom<T, HLEN>;
     // a single level writes the image row straight to HBM: no output buffer in LDS
     const size_t lds = (w.nlevels > 1 ? 3 : 2) * (size_t)G::buf_elems(b.n[1]) * sizeof(T);
-    if (lds > kLdsBudget1D) return 1;
+    if (lds > lds_budget_1d()) return 1;
     constexpr int NVh = Vec16<T>::N;
     bool pf = w.nlevels <= kInvMaxLev && (w.Nc % NVh) == 0 && ((uintptr_t)out & 15) == 0;
     for (int l = 0; l <= w.nlevels && pf; l++) {
