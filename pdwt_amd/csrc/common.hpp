@@ -158,6 +158,7 @@ enum KnobId {
     KN_COUNT
 };
 int knob(KnobId id);
+void stat_casc_spec(int inverse);  // (test statistics: a wave-program kernel was launched)
 int knob_set(const char* name, int value);  // PDWT_OK / PDWT_EINVAL (unknown name)
 int knob_get(const char* name, int* value);
 

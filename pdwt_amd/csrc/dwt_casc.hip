@@ -941,7 +941,10 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
                 xw = 0;  // the weighted split leaves the instantiated row counts: even split
             }
             if (!spec) xw = 0;
-            if (spec) k = k_fwd2d_casc<HLEN, 2, 16, true>;
+            if (spec) {
+                k = k_fwd2d_casc<HLEN, 2, 16, true>;
+                stat_casc_spec(0);
+            }
             const CascMap cm = {idiv_up(nwg, 8), strips, gy, xw, d_tbl};
             const dim3 grid((unsigned)(8 * cm.cpx), (unsigned)(d_tbl ? nimg : 1));
             if (lds > 64 * 1024) {  // opt-in once per (kernel, device), not per launch

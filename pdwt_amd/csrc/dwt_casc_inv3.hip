@@ -808,7 +808,10 @@ static int launch_inv_casc3(const CascInvBands& b, const CascInv3B& b3, float* o
         xw = 0;
     }
     if (!spec) xw = 0;
-    if (spec) k = k_inv2d_casc3<HLEN, 16, L3, true>;
+    if (spec) {
+        k = k_inv2d_casc3<HLEN, 16, L3, true>;
+        stat_casc_spec(1);
+    }
     const CascMap cm = {idiv_up(nwg, 8), strips, gy, xw, d_tbl};
     const dim3 grid((unsigned)(8 * cm.cpx), (unsigned)(d_tbl ? nimg : 1));
     if (lds > 64 * 1024) {  // opt-in once per (kernel, device), not per launch

@@ -103,10 +103,19 @@ int knob_set(const char* name, int value)
     return PDWT_EINVAL;
 }
 
+// launch statistics for tests (pdwt_debug_get("stat_casc_spec_fwd" / "stat_casc_spec_inv"): launches of the straight-line wave-program
+// kernels since the process started)
+std::atomic<int> g_stat_spec_fwd{0}, g_stat_spec_inv{0};
+void stat_casc_spec(int inverse) { (inverse ? g_stat_spec_inv : g_stat_spec_fwd).fetch_add(1, std::memory_order_relaxed); }
+
 int knob_get(const char* name, int* value)
 {
     std::call_once(g_knob_once, knob_init);
     if (!name || !value) return PDWT_EINVAL;
+    if (!strcmp(name, "stat_casc_spec_fwd") || !strcmp(name, "stat_casc_spec_inv")) {
+        *value = (name[15] == 'f' ? g_stat_spec_fwd : g_stat_spec_inv).load(std::memory_order_relaxed);
+        return PDWT_OK;
+    }
     for (int i = 0; i < KN_COUNT; i++) {
         if (!strcmp(name, g_knob_defs[i].name)) {
             *value = g_knob_vals[i];

@@ -1289,3 +1289,53 @@ def test_selfcheck_vmcnt_order():
     issued with EXEC = 0 included) holds on this device: pdwt_selfcheck_vmcnt_order() = 0 stale registers (tools/probes/vmcnt_order.hip in
     library form -- what a deployment on a new stepping runs once)."""
     assert pdwt_amd.hip().pdwt_selfcheck_vmcnt_order() == 0
+
+
+def test_cascade_wave_programs_geometries():
+    """The straight-line wave programs of the cascade kernels (kernel form SPEC of dwt_casc.hip / dwt_casc_inv3.hip): every geometry whose
+    per-wave row counts have an instantiation takes them -- heights around 4096 with any width, both filter lengths of the streamed inverse
+    (hlen 4 and 8), two and three levels -- and the result is the per-level kernels' bit for bit, including the waves whose rows wrap around
+    the image (first wave of the top workgroups, last wave of the bottom ones) and every strip count.  The launch statistics say which
+    cases really ran the wave programs (at least the C2 geometry must)."""
+    import ctypes as C
+    L = pdwt_amd.hip()
+
+    def stat(name):
+        v = C.c_int()
+        assert L.pdwt_debug_get(name, C.byref(v)) == 0
+        return v.value
+
+    rs = np.random.RandomState(31)
+    ran_f = ran_i = 0
+    for (nr, nc, wname, lev) in [(4096, 4096, "db4", 3), (4096, 4096, "db2", 3), (4096, 2048, "sym4", 3), (4096, 8192, "db4", 2), (4096, 1000 * 4, "db4", 3),
+                                 (4224, 4096, "db4", 3), (3968, 3072, "db4", 3), (4608, 4096, "db2", 2), (4096, 4096, "db3", 3), (4096, 6144, "db4", 4)]:
+        x = rs.uniform(-100, 100, (nr, nc)).astype(np.float32)
+        res = []
+        for casc in (1, 0):
+            with knobs(casc=casc, casc_min=0):
+                f0, i0 = stat(b"stat_casc_spec_fwd"), stat(b"stat_casc_spec_inv")
+                W = pdwt_amd.Wavelets(x, wname, lev)
+                W.forward()
+                c = W.coeffs
+                W.inverse()
+                res.append((c, W.get_image()))
+                if casc:
+                    ran_f += stat(b"stat_casc_spec_fwd") > f0
+                    ran_i += stat(b"stat_casc_spec_inv") > i0
+        for k, (a, b) in enumerate(zip(res[0][0], res[1][0])):
+            assert np.array_equal(a, b), (nr, nc, wname, lev, "band", k)
+        assert np.array_equal(res[0][1], res[1][1]), (nr, nc, wname, lev, "image")
+        assert band_err(res[0][1], x) <= 1e-5
+    assert ran_f >= 3 and ran_i >= 3, (ran_f, ran_i)
+    # the loop forms on the C2 geometry (casc_spec = 0) give the same bits as the wave programs
+    x = rs.uniform(0, 255, (4096, 4096)).astype(np.float32)
+    outs = []
+    for spec in (3, 0, 1, 2):
+        with knobs(casc_spec=spec):
+            W = pdwt_amd.Wavelets(x, "db4", 3)
+            W.forward()
+            c = W.coeffs
+            W.inverse()
+            outs.append((c, W.get_image()))
+    for o in outs[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(outs[0][0], o[0])) and np.array_equal(outs[0][1], o[1])
