@@ -138,6 +138,16 @@ save("pipe160x192_db20_L2_f64", input=x, wname=w, levels=L, kind="dwt2", nbands=
      norm1_before=n1_before, norm1_after=n1_after, recon=pywt.waverec2(c, w, MODE),
      recon_thresh=pywt.waverec2(ct, w, MODE), **pack(bands))
 
+# F8: one LONG bank per family in 2-D over several levels (the 72-wavelet fixture F7 pins the tap table through a level-1
+# 1-D transform only; these pin the long banks -- and the multi-level 2-D index arithmetic on them -- against pywt directly)
+case("long160x192_sym20_L2", rs(21).randn(160, 192), "sym20", 2, "dwt2", np.float32)
+case("long128x160_coif5_L2", rs(22).randn(128, 160), "coif5", 2, "dwt2", np.float64)
+case("long144x160_bior6.8_L3", rs(23).randn(144, 160), "bior6.8", 3, "dwt2", np.float64)
+case("long96x144_rbio6.8_L2", rs(24).randn(96, 144), "rbio6.8", 2, "dwt2", np.float32)
+case("long120x168_db14_L2", rs(25).randn(120, 168), "db14", 2, "dwt2", np.float64)
+case("long112x80_bior3.9_L2", rs(26).randn(112, 80), "bior3.9", 2, "dwt2", np.float64)
+case("swt96_sym8_L2", rs(27).randn(96, 96), "sym8", 2, "swt2", np.float32)
+
 # F7: every one of the 72 wavelets, one short 1D signal each (pins the filter table + index math
 # for every filter length 2..40) -- level 1 forward + the round trip.
 from importlib import import_module

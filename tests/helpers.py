@@ -68,4 +68,7 @@ GOLDEN_CASES = [
     "odd50x37_sym4_L2", "odd45x77_bior2.4_L2", "r96x160_coif2_L3", "swt112_db7_L3", "swt64_db3_L3", "swt48x80_db2_L2",
     "swt64_haar_L2", "swt1d_6x128_sym4_L3", "b1d_5x256_sym8_L4", "b1d_3x77_db3_L2_odd", "b1d_1x200_db5_L3",
     "haar64_L3", "haar37x51_L2_odd", "haar1d_3x77_L3_odd", "haar1d_4x64_L2_f32",
+    # one long bank per family, 2-D, several levels (F8 of tests/golden/make_golden.py)
+    "long160x192_sym20_L2", "long128x160_coif5_L2", "long144x160_bior6.8_L3", "long96x144_rbio6.8_L2", "long120x168_db14_L2", "long112x80_bior3.9_L2",
+    "swt96_sym8_L2",
 ]
