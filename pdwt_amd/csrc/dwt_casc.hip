@@ -907,7 +907,7 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
         while (W > 4 && (nr4 / gy) / W < HLEN / 2) W /= 2;
         while (gy > 1 && (nr4 / gy) / W < HLEN / 2) gy--;  // every wave needs >= HLEN/2 level-2 rows (see the kernel)
         if (gy >= 1 && (nr4 / gy) / W >= HLEN / 2) {
-            const int nwg = gy * strips;
+            int nwg = gy * strips;
             const size_t lds = (size_t)(W - 1) * REG;  // hand-off regions
             // (HLEN row registers in flight instead of HLEN/2 measured slower in this form too: 24.8 vs 24.6 us at W = 8)
             void (*k)(const float*, CascBands, int, int, int, float*, CascMap, TapsLH);
@@ -919,27 +919,34 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
             // the straight-line wave programs (kernel form SPEC) exist for waves of 4 or 5 level-2 rows whose workgroup's last wave has 1:
             // the kernel's split, replayed on the two chunk sizes that occur (C2: 73 or 74 level-2 rows over 16 waves)
             bool spec = nv2 && (knob(KN_CASC_SPEC) & 1) && 2 * 4 >= HLEN;
-            // XCD-weighted split (casc_chunk_start): only with the wave programs, and only if every workgroup still has them
-            int xw = spec ? knob(KN_CASC_XCDW) : 0;
-            for (int pass = 0; pass < 2; pass++) {
-                bool ok = spec;
-                for (int g = 0; g < gy && ok; g++)
-                    for (int st = 0; st < strips && ok; st++) {
-                        const int R = casc_chunk_start(g + 1, st, nr4, gy, strips, idiv_up(nwg, 8), xw) - casc_chunk_start(g, st, nr4, gy, strips, idiv_up(nwg, 8), xw);
-                        if (R < 16) {
-                            ok = false;
-                            break;
-                        }
+            auto spec_ok = [&](int gyq, int xwq) {
+                const int cpxq = idiv_up(gyq * strips, 8);
+                for (int g = 0; g < gyq; g++)
+                    for (int st = 0; st < strips; st++) {
+                        const int R = casc_chunk_start(g + 1, st, nr4, gyq, strips, cpxq, xwq) - casc_chunk_start(g, st, nr4, gyq, strips, cpxq, xwq);
+                        if (R < 16) return false;
                         const int E = std::min((3 * (HLEN - 2) + 3) / 4, R / 16 - 1);
                         const int base = (R + E) / 16, rem = (R + E) % 16;
-                        ok = base == 4 && R - (15 * base + std::min(15, rem)) == 1;
+                        if (base != 4 || R - (15 * base + std::min(15, rem)) != 1) return false;
                     }
-                if (ok || xw == 0) {
-                    spec = ok;
-                    break;
+                return true;
+            };
+            // Tall images (8192 rows and more: 18+ level-2 rows per wave with one workgroup per CU) run SEVERAL rounds of workgroups of the C2
+            // height instead, which have wave programs -- the situation of a batch of 4096-row images, whose workgroups are out of phase
+            // after the first round (tools/tall_sweep.py, db4 L3 pair, interleaved on one box: 8192^2 268 -> 255 us, 12288^2 592 -> 546, 16384^2
+            // 1135 -> 1031; 6144^2, 2.3 rounds: 135 -> 137, hence three rounds and more only).  knob casc_spec bit 2.
+            // Forward only: the inverse's per-workgroup prologue (three ring warm-ups) makes the same trade a loss (8192^2 pair +27 us).
+            if (spec && (knob(KN_CASC_SPEC) & 4) && knob(KN_CASC_WAVES) <= 0 && !d_tbl && (nr4 / gy) / 16 >= 8) {
+                const int gy2 = (nr4 + 36) / 73;
+                if (gy2 >= 3 * gy && spec_ok(gy2, 0)) {
+                    gy = gy2;
+                    nwg = gy * strips;
                 }
-                xw = 0;  // the weighted split leaves the instantiated row counts: even split
             }
+            // XCD-weighted split (casc_chunk_start): only with the wave programs, and only if every workgroup still has them
+            int xw = spec ? knob(KN_CASC_XCDW) : 0;
+            if (spec && xw != 0 && !spec_ok(gy, xw)) xw = 0;  // the weighted split leaves the instantiated row counts: even split
+            spec = spec && spec_ok(gy, xw);
             if (!spec) xw = 0;
             if (spec) {
                 k = k_fwd2d_casc<HLEN, 2, 16, true>;

@@ -67,7 +67,7 @@ static const KnobDef g_knob_defs[KN_COUNT] = {
     {"force_twopass", "PDWT_FORCE_TWOPASS", 0}, {"tiled_cols", "PDWT_TILED_COLS", 0},
     {"casc", "PDWT_CASC", 1}, {"casc_waves", "PDWT_CASC_WAVES", 0}, {"casc_nv", "PDWT_CASC_NV", 0},
     {"casc_min", "PDWT_CASC_MIN", 2048 * 2048}, {"casc_iwaves", "PDWT_CASC_IWAVES", 0}, {"casc_ipfd", "PDWT_CASC_IPFD", 1},
-    {"casc_wg", "PDWT_CASC_WG", 0}, {"casc_iwg", "PDWT_CASC_IWG", 0}, {"casc_l3", "PDWT_CASC_L3", 1}, {"casc_spec", "PDWT_CASC_SPEC", 3}, {"casc_xcdw", "PDWT_CASC_XCDW", 0}, {"dwt1d_lds_kb", "PDWT_DWT1D_LDS_KB", 80},
+    {"casc_wg", "PDWT_CASC_WG", 0}, {"casc_iwg", "PDWT_CASC_IWG", 0}, {"casc_l3", "PDWT_CASC_L3", 1}, {"casc_spec", "PDWT_CASC_SPEC", 7}, {"casc_xcdw", "PDWT_CASC_XCDW", 0}, {"dwt1d_lds_kb", "PDWT_DWT1D_LDS_KB", 80},
     {"stream", "PDWT_STREAM", 1}, {"stream_r", "PDWT_STREAM_R", 0}, {"stream_waves", "PDWT_STREAM_WAVES", 8192},
     {"stream_narrow", "PDWT_STREAM_NARROW", 2048 * 2048}, {"small", "PDWT_SMALL", 1},
     {"rows_tr", "PDWT_ROWS_TR", 1}, {"ring_r", "PDWT_RING_R", 0}, {"ring_waves", "PDWT_RING_WAVES", 4096},

@@ -1308,7 +1308,8 @@ def test_cascade_wave_programs_geometries():
     rs = np.random.RandomState(31)
     ran_f = ran_i = 0
     for (nr, nc, wname, lev) in [(4096, 4096, "db4", 3), (4096, 4096, "db2", 3), (4096, 2048, "sym4", 3), (4096, 8192, "db4", 2), (4096, 1000 * 4, "db4", 3),
-                                 (4224, 4096, "db4", 3), (3968, 3072, "db4", 3), (4608, 4096, "db2", 2), (4096, 4096, "db3", 3), (4096, 6144, "db4", 4)]:
+                                 (4224, 4096, "db4", 3), (3968, 3072, "db4", 3), (4608, 4096, "db2", 2), (4096, 4096, "db3", 3), (4096, 6144, "db4", 4),
+                                 (8192, 4096, "db4", 3)]:  # (tall: several rounds of workgroups of the C2 height, forward)
         x = rs.uniform(-100, 100, (nr, nc)).astype(np.float32)
         res = []
         for casc in (1, 0):
