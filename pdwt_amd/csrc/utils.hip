@@ -281,20 +281,31 @@ __global__ __launch_bounds__(kUThreads) void k_abs_sum(BandTable<T> tab, double*
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    // the LAST block to arrive adds the partials, in the fixed order the separate one-block launch used (k_abs_sum_final: 8 us of launch and
+    // boundary for 2048 doubles): publish the partial with a write-through store, drain it, take a ticket (cf. k_soft_thresh_sum)
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(partial + blockIdx.x, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int ticket = __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(partial + kMaxBlocks + 1), 1u, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (ticket == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (s_last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        double a = 0.0;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += kUThreads) a += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a = wave_sum(a);
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            partial[kMaxBlocks] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+            __hip_atomic_store(reinterpret_cast<unsigned int*>(partial + kMaxBlocks + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+        }
+    }
 }
 
-// second stage: one block, fixed summation order -> run-to-run deterministic
-__global__ __launch_bounds__(kUThreads) void k_abs_sum_final(const double* __restrict__ partial, int n, double* __restrict__ out)
-{
-    __shared__ double s_w[kUThreads / 64];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += kUThreads) acc += partial[i];
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) out[0] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-}
 
 // group soft threshold (src/common.cu:134-198): one scale factor per position from the l2 norm of the
 // detail coefficients there (and of the approximation at the last scale when asked), applied to all of them.
@@ -412,6 +423,10 @@ static double* partials(int* dev_out)
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_partials[dev]) {
         if (hipMalloc(&g_partials[dev], (kMaxBlocks + 8) * sizeof(double)) != hipSuccess) g_partials[dev] = nullptr;
+        else if (hipMemset(g_partials[dev], 0, (kMaxBlocks + 8) * sizeof(double)) != hipSuccess) {  // (the arrival counter of k_abs_sum starts at 0)
+            (void)hipFree(g_partials[dev]);
+            g_partials[dev] = nullptr;
+        }
     }
     return g_partials[dev];
 }
@@ -583,11 +598,6 @@ static int band_sum_double(T** c, pdwt_info w, double* out, int squares, int ref
         KTimer kt(K_ABS_SUM);
         if (vec) hipLaunchKernelGGL((k_abs_sum<T, true>), dim3(blocks), dim3(kUThreads), 0, stream(), tab, part);
         else hipLaunchKernelGGL((k_abs_sum<T, false>), dim3(blocks), dim3(kUThreads), 0, stream(), tab, part);
-        PDWT_CHECK_LAUNCH();
-    }
-    {
-        KTimer kt(K_ABS_SUM_FINAL);
-        hipLaunchKernelGGL(k_abs_sum_final, dim3(1), dim3(kUThreads), 0, stream(), (const double*)part, blocks, part + kMaxBlocks);
         PDWT_CHECK_LAUNCH();
     }
     if (scratch) return PDWT_OK;
