@@ -242,8 +242,9 @@ int pdwt_norm1_f32(float** d_coeffs, pdwt_info info, float* out);
 int pdwt_norm1_f64(double** d_coeffs, pdwt_info info, double* out);
 /* Threshold and norm in ONE pass over the bands: soft_thresh as above and, as a by-product, sum |c| over ALL bands (the
  * approximation band included, thresholded or not) of the thresholded coefficients -- what pdwt_norm1 would return right
- * after.  `d_scratch`: device buffer of pdwt_sum_scratch_doubles() doubles, zero-filled ONCE by the caller
- * (pdwt_memset) and then reusable for any number of calls on the library stream; no host synchronisation.
+ * after.  `d_scratch`: device buffer of pdwt_sum_scratch_doubles() doubles, ANY contents (the entry point resets the
+ * kernels' arrival counter on the library stream in front of every launch; no zero-fill is required of the caller),
+ * reusable for any number of calls on the library stream -- one reduction at a time per buffer; no host synchronisation.
  * pdwt_sum_scratch_read copies the result out (synchronises the stream).  The block partials are added in a fixed
  * order by the last block to finish: run-to-run deterministic. */
 size_t pdwt_sum_scratch_doubles(void);
@@ -254,7 +255,7 @@ int pdwt_sum_scratch_read(const double* d_scratch, double* out);
 int pdwt_norm1_as_double_f32(float** d_coeffs, pdwt_info info, double* out);
 int pdwt_norm1_as_double_f64(double** d_coeffs, pdwt_info info, double* out);
 /* the same reduction, ENQUEUED only: partial sums and result go to `d_scratch` (pdwt_sum_scratch_doubles() doubles, owned by
- * the caller); pdwt_sum_scratch_read fetches the value later.  Lets a host thread start the reductions of several devices
+ * the caller, any contents -- see above); pdwt_sum_scratch_read fetches the value later.  Lets a host thread start the reductions of several devices
  * before it waits for any of them (include/wt_batch.h). */
 int pdwt_norm1_enqueue_f32(float** d_coeffs, pdwt_info info, double* d_scratch);
 int pdwt_norm1_enqueue_f64(double** d_coeffs, pdwt_info info, double* d_scratch);

@@ -117,6 +117,10 @@ class Wavelets {
      * reduction before it reads the first one and adds the doubles. */
     void norm1_begin();
     double norm1_end();
+    /* ADDITION: 1 while the double at pdwt_sum_result_index() of the scratch below is (or, stream-ordered, will be) this instance's
+     * CURRENT sum|c| -- norm1_begin() enqueued its reduction, or the one-pass threshold's value is still valid; 0 when norm1_begin()
+     * failed or was never called: wt_batch.h then adds the shards' sums on the host instead of all-reducing a stale double. */
+    int norm1_pending() const;
     /* ADDITION: device address of the instance's reduction scratch (allocated on first use; pdwt_sum_scratch_doubles() doubles on the
      * instance's device): after norm1_begin() the double at element pdwt_sum_result_index() is this instance's sum|c| -- what
      * wt_batch.h hands to the RCCL all-reduce across the devices of a batch.  0 on failure. */

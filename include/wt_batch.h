@@ -121,6 +121,8 @@ class WaveletsBatch {
             if (!shard[s]) return false; /* (an empty shard has no device buffer to contribute: host sum) */
             for (size_t t = 0; t < dv.size(); t++)
                 if (dv[t] == devs_[s]) return false;
+            /* a shard whose norm1_begin() failed (or found no scratch) holds a STALE double: host sum (norm1_end() falls back to norm1()) */
+            if (!shard[s]->norm1_pending()) return false;
             double* sc = (double*)shard[s]->norm1_scratch_int_ptr();
             if (!sc) return false;
             dv.push_back(devs_[s]);

@@ -98,6 +98,10 @@ def hip():
     L.pdwt_batch2d_inverse_f32.argtypes = [vp, vp]
     L.pdwt_batch2d_destroy.argtypes = [vp]
     L.pdwt_clock_probe_dump.argtypes = [vp, ci]
+    L.pdwt_sum_scratch_doubles.restype = sz
+    L.pdwt_sum_result_index.restype = sz
+    L.pdwt_sum_spare_index.restype = sz
+    L.pdwt_sum_scratch_read.argtypes = [vp, C.POINTER(C.c_double)]
     L.pdwt_clock_probe_read.argtypes = [ci, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.pdwt_debug_set.argtypes = [C.c_char_p, ci]
     L.pdwt_debug_get.argtypes = [C.c_char_p, C.POINTER(ci)]
@@ -117,6 +121,7 @@ def hip():
         getattr(L, "pdwt_norm1_" + sfx).argtypes = [PP, Info, P]
         getattr(L, "pdwt_norm1_as_double_" + sfx).argtypes = [PP, Info, C.POINTER(C.c_double)]
         getattr(L, "pdwt_norm1_enqueue_" + sfx).argtypes = [PP, Info, vp]
+        getattr(L, "pdwt_soft_thresh_sum_" + sfx).argtypes = [PP, ct, Info, ci, ci, vp]
         for n in ("hard_thresh", "group_soft_thresh"):
             getattr(L, "pdwt_%s_%s" % (n, sfx)).argtypes = [PP, ct, Info, ci, ci]
         for n in ("proj_linf", "shrink"):

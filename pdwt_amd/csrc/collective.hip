@@ -7,13 +7,24 @@
 // RCCL cannot take (repeated devices) -- reports PDWT_ENOTSUP so that the caller adds the doubles on the host instead.
 // Reference: none (the reference is single-GPU, TODO.txt:15).
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <map>
 #include <mutex>
 #include <vector>
 
 #include "common.hpp"
+
+// The few RCCL declarations this file needs, stated here instead of #include <rccl/rccl.h>: the library is a run-time option (dlopen),
+// so its development headers must not be a BUILD requirement of libpdwt_hip.so.  Values are those of the stable NCCL 2.x ABI
+// (rccl.h: ncclSuccess = 0, ncclInvalidArgument = 4, ncclSum = 0, ncclFloat64 = 8); tests/test_cabi_symbols.py checks them, and the
+// function-pointer signatures below, against the header when the image has one.
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+static constexpr ncclResult_t ncclSuccess = 0, ncclInvalidArgument = 4;
+static constexpr ncclRedOp_t ncclSum = 0;
+static constexpr ncclDataType_t ncclDouble = 8;
 
 namespace pdwt {
 namespace {
@@ -48,7 +59,9 @@ RcclApi& rccl()
     return api;
 }
 std::mutex g_comm_mu;
-std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms;  // one communicator set per device list (kept for the life of the process)
+// one communicator set per device list (kept for the life of the process); an EMPTY vector records a device list ncclCommInitAll refused,
+// so that every later norm1() of that batch takes the host sum at once instead of paying for the init again
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms;
 }  // namespace
 }  // namespace pdwt
 
@@ -80,10 +93,12 @@ int pdwt_rccl_allreduce_sum_f64(int n, const int* devices, const double* const* 
         (void)hipSetDevice(prev);
         if (r != ncclSuccess) {
             set_last_error(hipErrorUnknown, api.GetErrorString ? api.GetErrorString(r) : "ncclCommInitAll", __FILE__, __LINE__);
+            g_comms.emplace(devs, std::vector<ncclComm_t>());
             return PDWT_ENOTSUP;
         }
         it = g_comms.emplace(devs, comms).first;
     }
+    if (it->second.empty()) return PDWT_ENOTSUP;  // (refused before)
     ncclResult_t r = api.GroupStart();
     for (int i = 0; i < n && r == ncclSuccess; i++) {
         if (hipSetDevice(devs[i]) != hipSuccess) {

@@ -378,21 +378,25 @@ namespace {
 typedef float probe_v4f __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_bw_probe(const probe_v4f* __restrict__ in, probe_v4f* __restrict__ out, size_t n4, int mode)
 {
-    const size_t G = gridDim.x, per = (n4 / 256 + G - 1) / G;  // 4 KiB blocks per workgroup
+    // 4 KiB blocks per workgroup (rounded up: the last workgroups of an uneven split find idx >= n4 and do nothing, and the tail of a
+    // byte count that is not a multiple of 4 KiB is the last, partial block -- every 16-byte element is moved exactly once)
+    const size_t G = gridDim.x, nblk = (n4 + 255) / 256, per = (nblk + G - 1) / G;
     probe_v4f acc = {0.f, 0.f, 0.f, 0.f};
     for (size_t k = 0; k < per; k += 8) {
         probe_v4f r[8];
         size_t idx[8];
+        bool on[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             idx[u] = (blockIdx.x * per + k + u) * 256 + threadIdx.x;
-            if (mode != 2) r[u] = in[idx[u] < n4 ? idx[u] : threadIdx.x];
+            on[u] = (k + u < per) && idx[u] < n4;  // (k + u >= per would be the NEXT workgroup's chunk: moved twice)
+            if (mode != 2) r[u] = in[on[u] ? idx[u] : threadIdx.x];
             else r[u] = probe_v4f{1.f, 2.f, 3.f, (float)u};
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             if (mode == 1) acc += r[u];
-            else if (idx[u] < n4) out[idx[u]] = r[u];
+            else if (on[u]) out[idx[u]] = r[u];
         }
     }
     if (mode == 1 && acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc;  // (never true: keeps the loads alive)

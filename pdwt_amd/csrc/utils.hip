@@ -415,6 +415,15 @@ __global__ __launch_bounds__(kUThreads) void k_circshift(const T* __restrict__ i
 static std::mutex g_mu;
 static std::mutex g_red_mu[64];
 static double* g_partials[64] = {};
+// A CALLER's scratch (pdwt_norm1_enqueue_*, pdwt_soft_thresh_sum_*): the last-block ticket of the reduction kernels lives at element
+// kMaxBlocks + 1 and must be 0 when a launch starts.  The kernels leave it at 0, but nothing says what a caller's buffer held before its
+// first use (a non-zero ticket never matches gridDim.x - 1: the result slot would keep its old value, with PDWT_OK) -- so it is zeroed
+// here, stream-ordered in front of every launch on such a buffer (8 bytes; the library's own per-device partials skip it).
+static int reset_ticket(double* scratch)
+{
+    PDWT_HIP_TRY(hipMemsetAsync(scratch + kMaxBlocks + 1, 0, sizeof(double), stream()));
+    return PDWT_OK;
+}
 static double* partials(int* dev_out)
 {
     int dev = 0;
@@ -423,7 +432,9 @@ static double* partials(int* dev_out)
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_partials[dev]) {
         if (hipMalloc(&g_partials[dev], (kMaxBlocks + 8) * sizeof(double)) != hipSuccess) g_partials[dev] = nullptr;
-        else if (hipMemset(g_partials[dev], 0, (kMaxBlocks + 8) * sizeof(double)) != hipSuccess) {  // (the arrival counter of k_abs_sum starts at 0)
+        // (the arrival counter of k_abs_sum starts at 0; zeroed ON THE LIBRARY STREAM: a NULL-stream memset is not ordered with a
+        // non-blocking library stream, PDWT_STREAM_NONBLOCKING=1 / pdwt_set_stream)
+        else if (hipMemsetAsync(g_partials[dev], 0, (kMaxBlocks + 8) * sizeof(double), stream()) != hipSuccess) {
             (void)hipFree(g_partials[dev]);
             g_partials[dev] = nullptr;
         }
@@ -488,8 +499,8 @@ static int ew_bands(T** c, T beta, pdwt_info w, int do_thresh_appcoeffs, int nor
     return PDWT_OK;
 }
 
-// soft threshold + sum|c| of the result over all bands in `scratch` (device, pdwt_sum_scratch_doubles() doubles,
-// zero-initialised once by the caller); nothing is copied to the host and nothing synchronises
+// soft threshold + sum|c| of the result over all bands in `scratch` (device, pdwt_sum_scratch_doubles() doubles, any
+// contents: reset_ticket); nothing is copied to the host and nothing synchronises
 template <typename T>
 static int soft_thresh_sum(T** c, T beta, pdwt_info w, int do_thresh_appcoeffs, int normalize, double* scratch)
 {
@@ -524,6 +535,7 @@ static int soft_thresh_sum(T** c, T beta, pdwt_info w, int do_thresh_appcoeffs, 
     }
     const unsigned int total = tab.chunk0[tab.nb];
     const int blocks = (int)(total < (unsigned)kMaxBlocks ? (total ? total : 1) : (unsigned)kMaxBlocks);
+    if (const int rc = reset_ticket(scratch); rc != PDWT_OK) return rc;
     KTimer kt(K_THRESH_SUM);
     if (vec) hipLaunchKernelGGL((k_soft_thresh_sum<T, true>), dim3(blocks), dim3(kUThreads), 0, stream(), tab, scratch);
     else hipLaunchKernelGGL((k_soft_thresh_sum<T, false>), dim3(blocks), dim3(kUThreads), 0, stream(), tab, scratch);
@@ -594,6 +606,9 @@ static int band_sum_double(T** c, pdwt_info w, double* out, int squares, int ref
     if (!scratch) red_lock.lock();  // the per-device partials are shared by every instance on that device
     const unsigned int total = tab.chunk0[tab.nb];
     const int blocks = (int)(total < (unsigned)kMaxBlocks ? (total ? total : 1) : (unsigned)kMaxBlocks);
+    if (scratch) {
+        if (const int rc = reset_ticket(scratch); rc != PDWT_OK) return rc;
+    }
     {
         KTimer kt(K_ABS_SUM);
         if (vec) hipLaunchKernelGGL((k_abs_sum<T, true>), dim3(blocks), dim3(kUThreads), 0, stream(), tab, part);

@@ -521,6 +521,15 @@ void Wavelets::norm1_begin()
     st->norm_enqueued = (rc == PDWT_OK);
 }
 
+int Wavelets::norm1_pending() const
+{
+    if (state == W_CREATION_ERROR) return 0;
+    const wstate_t* st = WS(filters_);
+    if (!st || !st->d_sum) return 0;
+    const bool cached = st->sum_valid && !st->raw_ptr_taken && norm_in_threshold(st);
+    return (cached || st->norm_enqueued) ? 1 : 0;
+}
+
 double Wavelets::norm1_end()
 {
     ON_MY_DEVICE();

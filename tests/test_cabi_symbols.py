@@ -105,3 +105,24 @@ def test_header_is_plain_c(tmp_path):
     cpp.write_text('#include "wt.h"\nint main() { return sizeof(Wavelets) > 0 ? 0 : 1; }\n')
     for flags in ([], ["-DDOUBLEPRECISION"]):
         subprocess.check_call([shutil.which("g++") or "g++", "-std=c++11", "-Wall", "-I", inc, "-fsyntax-only", str(cpp)] + flags)
+
+
+def test_rccl_abi_constants_match_the_header_when_present():
+    """collective.hip states the few RCCL declarations it needs itself (no build dependency on the RCCL headers: the library is
+    dlopen'ed).  Where the image ships rccl.h, its enumerators and prototypes must be the ones stated there."""
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("no rccl.h in this image")
+    h = open(hdr).read()
+    src = open(os.path.join(ROOT, "pdwt_amd", "csrc", "collective.hip")).read()
+    assert "#include <rccl" not in src
+    for name, val in (("ncclSuccess", 0), ("ncclInvalidArgument", 4), ("ncclSum", 0), ("ncclDouble", 8)):
+        m = re.search(r"\b%s\s*=\s*(\d+)" % name, h)
+        assert m and int(m.group(1)) == val, name
+        assert re.search(r"\b%s = %d\b" % (name, val), src), name
+    flat = re.sub(r"\s+", " ", h)
+    assert "ncclResult_t ncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist);" in flat
+    assert ("ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, "
+            "ncclComm_t comm, hipStream_t stream);") in flat
+    assert "ncclResult_t ncclCommDestroy(ncclComm_t comm);" in flat
+    assert "ncclResult_t ncclGroupStart();" in flat and "ncclResult_t ncclGroupEnd();" in flat

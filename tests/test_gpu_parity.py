@@ -489,6 +489,43 @@ def test_utilities_vs_pywt_golden():
                     assert band_err(g, e) <= tol, (prefix, k, band_err(g, e))
 
 
+def test_reductions_on_uninitialised_caller_scratch():
+    """ADVICE r4 (utils.hip): pdwt_norm1_enqueue_* / pdwt_soft_thresh_sum_* take a CALLER's scratch; the last-block ticket inside it must
+    not depend on what the buffer held before (a non-zero ticket used to leave the result slot stale, with PDWT_OK).  Garbage-filled
+    scratch, several calls in a row, both precisions."""
+    import ctypes as C
+    L = pdwt_amd.hip()
+    rs = np.random.RandomState(77)
+    for dt, sfx, ct, tol in ((np.float32, "f32", C.c_float, 1e-6), (np.float64, "f64", C.c_double, 1e-12)):
+        x = (rs.randn(96, 160) * 10).astype(dt)
+        W = pdwt_amd.Wavelets(x, "db3", 3)
+        W.forward()
+        want = W.norm1_f64()
+        nb = W.nbands
+        P = C.POINTER(ct)
+        tab = (P * nb)(*[C.cast(C.c_void_p(W.coeff_int_ptr(k)), P) for k in range(nb)])
+        nbytes = L.pdwt_sum_scratch_doubles() * 8
+        L.pdwt_malloc.restype = C.c_void_p
+        sc = C.c_void_p(L.pdwt_malloc(C.c_size_t(nbytes)))
+        assert sc.value
+        try:
+            for fill in (0xFF, 0x5A, 0x00):
+                assert L.pdwt_memset(sc, fill, C.c_size_t(nbytes)) == 0
+                for _ in range(2):
+                    out = C.c_double(-1.0)
+                    assert getattr(L, "pdwt_norm1_enqueue_" + sfx)(tab, W.info, sc) == 0
+                    assert L.pdwt_sum_scratch_read(sc, C.byref(out)) == 0
+                    assert abs(out.value - want) <= tol * want, (sfx, fill, out.value, want)
+            assert L.pdwt_memset(sc, 0xA5, C.c_size_t(nbytes)) == 0
+            out = C.c_double(-1.0)
+            assert getattr(L, "pdwt_soft_thresh_sum_" + sfx)(tab, ct(0.7), W.info, 0, 0, sc) == 0
+            assert L.pdwt_sum_scratch_read(sc, C.byref(out)) == 0
+            want2 = W.norm1_f64()  # (the bands were thresholded in place: the plain reduction of what is there now)
+            assert abs(out.value - want2) <= tol * want2, (sfx, out.value, want2)
+        finally:
+            L.pdwt_free(sc)
+
+
 def test_add_wavelet_and_error_codes():
     rs = np.random.RandomState(51)
     x, y = rs.randn(64, 96).astype(np.float32), rs.randn(64, 96).astype(np.float32)
