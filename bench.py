@@ -94,10 +94,61 @@ def algorithmic_bytes(cfg, levels_eff):
     return step, per_kernel
 
 
+def usable_cores():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota of the container (the round-4 GPU boxes show
+    256 hardware threads but grant `cpu.max = 1600000 100000` = 16 CPUs: every OpenMP team beyond that is throttled, which is what the
+    collapse of round 4's `by_threads` above 16 threads was)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return (max(1, min(n, int(quota + 0.5))) if quota else n), n, quota
+
+
+_CPU_CHILD = r"""
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+cfg = json.loads(sys.argv[2]); Nr, Nc, cands, per = int(sys.argv[3]), int(sys.argv[4]), json.loads(sys.argv[5]), float(sys.argv[6])
+import numpy as np
+from oracle import oracle as orc
+x = np.random.RandomState(0).uniform(0, 255, (Nr, Nc)).astype(cfg["dtype"])
+W = orc.OracleWavelets(x, cfg["wname"], cfg["levels"], do_swt=cfg["do_swt"], ndim=cfg["ndim"])
+def pair():
+    W.forward()
+    if cfg["extra"]:
+        W.soft_threshold(0.5)
+        W.norm1_f64()
+    W.inverse()
+res = {}
+for nthreads in cands:
+    used = orc.set_num_threads(nthreads)
+    pair()  # warm (page faults -- first touch by the team that will use the pages --, thread team)
+    t0 = time.perf_counter(); pair(); t1 = time.perf_counter() - t0
+    reps = int(max(1, min(200, per / max(t1, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pair()
+    dt = (time.perf_counter() - t0) / reps
+    res[used] = dict(value=Nr * Nc / dt / 1e6, threads=used, reps=reps, s_per_pair=dt)
+print(json.dumps({"res": res, "levels": W.info.nlevels}))
+"""
+
+
 def cpu_baseline(cfg, seconds_budget):
-    """Time the CPU oracle (kind 'port') on this host's cores on a bounded sample of the workload."""
-    import numpy as np
-    from oracle import oracle as orc
+    """Time the CPU oracle (kind 'port') on this host's cores on a bounded sample of the workload.  Runs in a process of its own: the
+    bench process has torch's libgomp loaded and configured, and OpenMP reads its environment once -- the child gets passive waiting
+    (a team larger than the CPU quota must not spin its quota away) and spread binding over the cores."""
+    import subprocess
     Nr, Nc = cfg["Nr"], cfg["Nc"]
     scale = 1
     # keep one pair at a few seconds at most: shrink the sample for the heavy configs
@@ -109,42 +160,32 @@ def cpu_baseline(cfg, seconds_budget):
         Nr //= 2
         Nc //= 2
         scale *= 4
-    rs = np.random.RandomState(0)
-    x = rs.uniform(0, 255, (Nr, Nc)).astype(cfg["dtype"])
-    W = orc.OracleWavelets(x, cfg["wname"], cfg["levels"], do_swt=cfg["do_swt"], ndim=cfg["ndim"])
-
-    def pair():
-        W.forward()
-        if cfg["extra"]:
-            W.soft_threshold(0.5)
-            W.norm1_f64()
-        W.inverse()
-
-    ncores = os.cpu_count() or 1
-    res = {}
-    cands = sorted({1, ncores} | {t for t in (8, 16, 32, 64, 128) if t < ncores})
+    usable, affinity, quota = usable_cores()
+    host = os.cpu_count() or 1
+    # single thread, the CPUs the container is granted ("all cores" of THIS process), and teams below / beyond that for the shape of the curve
+    cands = sorted({1, usable} | {t for t in (usable // 2, 2 * usable, 4 * usable) if 1 <= t <= host})
     per = seconds_budget / (len(cands) + 2.0)
-    for nthreads in cands:
-        used = orc.set_num_threads(nthreads)
-        pair()  # warm (page faults, thread team)
-        t0 = time.perf_counter()
-        pair()
-        t1 = time.perf_counter() - t0
-        reps = int(max(1, min(200, per / max(t1, 1e-6))))
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            pair()
-        dt = (time.perf_counter() - t0) / reps
-        res[used] = dict(value=Nr * Nc / dt / 1e6, threads=used, reps=reps, s_per_pair=dt)
+    env = dict(os.environ, OMP_WAIT_POLICY="passive", OMP_PROC_BIND="spread", OMP_PLACES="cores")
+    env.pop("OMP_NUM_THREADS", None)
+    ccfg = {k: cfg[k] for k in ("dtype", "wname", "levels", "do_swt", "ndim", "extra")}
+    out = subprocess.run([sys.executable, "-c", _CPU_CHILD, ROOT, json.dumps(ccfg), str(Nr), str(Nc), json.dumps(cands), str(per)],
+                         capture_output=True, text=True, timeout=max(120.0, 20.0 * seconds_budget), env=env)
+    if out.returncode != 0:
+        raise RuntimeError("cpu_baseline child failed: " + out.stderr[-500:])
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    res = {int(k): v for k, v in j["res"].items()}
     best = max(res.values(), key=lambda r: r["value"])
     pywt_ref = pywt_timing(cfg, Nr, Nc) if not cfg["extra"] else None
     return {
         "pywt": pywt_ref,
         "value": round(best["value"], 2), "unit": cfg["unit"], "cores": best["threads"], "kind": "port",
-        "sample": "%d x fwd+inv of a %dx%d %s %s L%d input (%s of the GPU workload's pixels per pair), oracle/pdwt_oracle.c with OpenMP, "
-                  "best of thread counts %s" % (best["reps"], Nr, Nc, cfg["dtype"], cfg["wname"], W.info.nlevels,
-                                                "all" if scale == 1 else "1/%d" % scale, sorted(res)),
-        "single_thread_value": round(res[1]["value"], 2), "host_cores": ncores,
+        "sample": "%d x fwd+inv of a %dx%d %s %s L%d input (%s of the GPU workload's pixels per pair), oracle/pdwt_oracle.c with OpenMP "
+                  "(own process: OMP_WAIT_POLICY=passive, OMP_PROC_BIND=spread, OMP_PLACES=cores), best of thread counts %s"
+                  % (best["reps"], Nr, Nc, cfg["dtype"], cfg["wname"], j["levels"], "all" if scale == 1 else "1/%d" % scale, sorted(res)),
+        "single_thread_value": round(res[1]["value"], 2),
+        "all_cores_value": round(res[usable]["value"], 2) if usable in res else None, "usable_cores": usable,
+        "host_cores": host, "affinity_cores": affinity, "cgroup_cpu_quota": quota,
+        "note": "usable_cores = min(affinity, cgroup cpu.max quota): what 'all cores' means for this process; teams beyond it share the quota",
         "by_threads": {str(k): round(v["value"], 1) for k, v in sorted(res.items())},
     }
 
@@ -692,9 +733,16 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     global _SAMPLER
-    if rank == 0:
-        _SAMPLER = PowerSampler(local_rank)
-        time.sleep(0.5)  # (the helper imports amdsmi)
+    # every rank samples the clock and socket power of ITS device (N > 1: eight GPUs drawing power at once is what a scaling run is about)
+    _SAMPLER = PowerSampler(local_rank)
+    time.sleep(0.5)  # (the helper imports amdsmi)
+    # the size of the collective group, from the communicator itself: an all-reduce of one 1 per rank over the backend the batch split uses
+    rccl_ranks, coll_backend = None, None
+    if world > 1:
+        coll_backend = dist.get_backend()
+        one = torch.ones(1, device="cuda" if coll_backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(one)
+        rccl_ranks = int(round(float(one.item())))
     cfg = CONFIGS[args.config]
     res = run_config(args.config, args, L, torch, dist, rank, world, args.steps, args.warmup, args.settle_ms, args.cpu_seconds, not args.no_roofline)
 
@@ -709,6 +757,31 @@ def main():
             except Exception as e:  # a failing side run must not take the headline line with it -- but it must be visible
                 others[name] = {"error": repr(e)}
             torch.cuda.empty_cache()
+    # N > 1: the headline workload lives in every GPU's Infinity Cache, so its weak-scaling curve says little about N GPUs streaming from HBM
+    # at once.  Every rank therefore also times, briefly, the two workloads that DO stream: c2_batch (16 distinct images per GPU through the
+    # batched entry) and its C4 shard (8192 x 8192 rows of the batched-1D array) -- whole-job values, max over ranks, like the headline.
+    streaming = None
+    if world > 1 and not args.no_others and args.config == "c2":
+        streaming = {}
+        for name in ("c2_batch", "c4"):
+            st, wu, settle, _ = OTHER_RUNS[name]
+            try:
+                r = run_config(name, args, L, torch, dist, rank, world, st, wu, settle, 0.0, False)
+                streaming[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "gpu_ms_per_step", "ms_per_image_pair", "steps", "warmup", "workload", "sanity", "power")}
+            except Exception as e:
+                streaming[name] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+    # per-rank clock / power means of the headline's timed region, gathered as numbers
+    per_rank = None
+    if world > 1:
+        pw = res.get("power") or {}
+        mine = torch.tensor([float((pw.get("sclk_mhz") or {}).get("mean") or -1.0), float((pw.get("socket_w") or {}).get("mean") or -1.0)],
+                            device="cuda" if coll_backend == "nccl" else "cpu", dtype=torch.float64)
+        allp = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        per_rank = {"sclk_mhz_mean": [None if float(t[0]) < 0 else float(t[0]) for t in allp],
+                    "socket_w_mean": [None if float(t[1]) < 0 else float(t[1]) for t in allp],
+                    "what": "amdsmi means of each rank's own device inside the headline's timed region (null: no amdsmi on that rank)"}
 
     if rank == 0:
         line = {
@@ -724,7 +797,18 @@ def main():
             "sanity": res["sanity"], "roofline": res["roofline"], "cpu_baseline": res["cpu_baseline"], "power": res["power"],
             "extra_timing": res.get("extra_timing"), "clock_probe": res.get("clock_probe"),
             "kernels": res["kernels"], "other_configs": others,
+            "rccl_ranks": rccl_ranks if coll_backend == "nccl" else None, "collective": {"backend": coll_backend, "ranks": rccl_ranks} if world > 1 else None,
+            "per_rank": per_rank,
         }
+        # the HBM-streaming throughputs next to the cache-resident headline, at every N: whole-job Mpixels/s of 16 distinct images per GPU
+        # through the batched entry, and whole-job Msamples/s of the C4 shards (N = 1: the same numbers as other_configs.c2_batch / .c4)
+        src = streaming if world > 1 else (others or {})
+        cbs, c4s = src.get("c2_batch") or {}, src.get("c4") or {}
+        line["value_streaming"] = cbs.get("value")
+        line["ms_per_image_pair_streaming"] = cbs.get("ms_per_image_pair")
+        line["c4_value"] = c4s.get("value")
+        line["c4_ms_per_step"] = c4s.get("ms_per_step")
+        line["streaming_runs"] = streaming
         # both memory regimes of the headline workload at the top level of `roofline`: the figures above are one image living in the
         # Infinity Cache; `streaming` is the same transform on 16 distinct images in one batched call (pdwt_batch2d_*), 4.3 GB per
         # step: the number that is an HBM number

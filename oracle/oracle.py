@@ -59,7 +59,7 @@ def lib():
         _LIB.orc_norm1_f32.restype = C.c_double
         _LIB.orc_norm1_f64.restype = C.c_double
         # parity tests run many small problems: a 256-thread OpenMP team per loop is pure overhead.
-        # bench.py's cpu_baseline leg raises this to all cores explicitly.
+        # The full-size tests raise this to usable_cores(); bench.py's cpu_baseline leg times its own thread counts in its own process.
         _LIB.orc_set_num_threads(min(16, os.cpu_count() or 1))
     return _LIB
 
@@ -78,6 +78,19 @@ def ilog2(i):  # w_ilog2, src/utils.cu:14-20
 
 def set_num_threads(n):
     return lib().orc_set_num_threads(int(n))
+
+
+def usable_cores(cap=64):
+    """CPUs this process is really granted: the affinity mask capped by the container's cgroup CPU quota (a 256-thread host that grants
+    16 CPUs throttles any larger OpenMP team), at most `cap`.  What the full-size parity tests give the oracle's team."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
 
 
 def max_threads():

@@ -183,8 +183,12 @@ static void FN(swt_ana_lines)(const T* x, ptrdiff_t ls, ptrdiff_t es, int nlines
 
 /* ---- a-trous synthesis ---------------------------------------------------------------------
  * Follows w_kern_inverse_swt_pass1/2 (src/separable.cu:553-589, 593-626), SURVEY A-4:
- *   c = (hlen/2)*f;  out[g] = sum_j a[(g-c+f*j) mod n]*(IL[hlen-1-j]/2) + sum_j d[..]*(IH[..]/2)
- * (the reference writes (a*IL)/2; halving is exact, so tap/2 first is bit-identical).          */
+ *   c = (hlen/2)*f;  out[g] = sum_j (a[(g-c+f*j) mod n]*IL[hlen-1-j])/2 + sum_j (d[..]*IH[..])/2
+ * The reference writes `res += a * IL[..] / 2` (src/separable.cu:581-584, 621-622): the PRODUCT is rounded, halved (exact) and then
+ * added -- the divide sits between the multiply and the add, so nvcc cannot contract them into one FMA.  Restated literally here
+ * (round 5; until then the oracle pre-halved the tap and used one FMA, which differs from this by the rounding of the product: up
+ * to one ulp per tap, inside the 1e-5 bar and pinned to pywt.iswt2 either way -- but not "bit-identical", as its comment claimed).
+ * The HIP kernels keep pre-halved taps in one FMA per tap (deliberate deviation).                          */
 static void FN(swt_syn_lines)(const T* a, const T* d, ptrdiff_t ls, ptrdiff_t es, int nlines, int n,
                               T* out, ptrdiff_t ols, ptrdiff_t oes,
                               int hlen, const T* FIL, const T* FIH, int level)
@@ -201,10 +205,11 @@ static void FN(swt_syn_lines)(const T* a, const T* d, ptrdiff_t ls, ptrdiff_t es
             for (int l = 0; l < nlines; l++) { sa[l] = 0; sd[l] = 0; }
             for (int j = 0; j < ntaps; j++) {
                 const ptrdiff_t src = (ptrdiff_t)orc_wrap(g - c + f * j, n) * es;
-                const T fl = FIL[hlen - 1 - j] / 2, fh = FIH[hlen - 1 - j] / 2;
+                const T fl = FIL[hlen - 1 - j], fh = FIH[hlen - 1 - j];
                 for (int l = 0; l < nlines; l++) {
-                    sa[l] = FMA(a[src + l], fl, sa[l]);
-                    sd[l] = FMA(d[src + l], fh, sd[l]);
+                    const T pa = a[src + l] * fl, pd = d[src + l] * fh; /* rounded products ... */
+                    sa[l] += pa / 2;                                     /* ... halved exactly, then added */
+                    sd[l] += pd / 2;
                 }
             }
             T* po = out + (ptrdiff_t)g * oes;
@@ -220,8 +225,9 @@ static void FN(swt_syn_lines)(const T* a, const T* d, ptrdiff_t ls, ptrdiff_t es
                 T sa = 0, sd = 0;
                 for (int j = 0; j < ntaps; j++) {
                     const ptrdiff_t src = (ptrdiff_t)orc_wrap(g - c + f * j, n) * es;
-                    sa = FMA(pa[src], FIL[hlen - 1 - j] / 2, sa);
-                    sd = FMA(pd[src], FIH[hlen - 1 - j] / 2, sd);
+                    const T qa = pa[src] * FIL[hlen - 1 - j], qd = pd[src] * FIH[hlen - 1 - j];
+                    sa += qa / 2;
+                    sd += qd / 2;
                 }
                 out[(ptrdiff_t)l * ols + (ptrdiff_t)g * oes] = sa + sd;
             }

@@ -155,9 +155,21 @@ enum KnobId {
     KN_F64_LDS_SKEW,       // dwt_lds.hip kernels, two workgroups per CU: % of a chunk pair's rows that go to the workgroup dispatched first (0 = even)
     KN_NORM2SQ_REF1D,      // 1: norm2sq of a 1-D transform adds sum|d| of the detail bands like the reference (src/wt.cu:389) instead of sum d^2
     KN_NORM_IN_THRESHOLD,  // sum|c| computed inside soft_threshold() and returned by the next norm1(): -1 = per instance (set_norm_cache), 0 = never, 1 = always
+    KN_SELFCHECK,          // 1: the first use of a hand-counted-wait kernel on a device runs pdwt_selfcheck_vmcnt_order() (cached; failure -> compiler-counted kernels); 0: trust the build guard
+    KN_DWT1D_F64,          // 0: per-level row kernels for batched 1-D in double precision instead of the fused all-levels kernels
+    KN_SWTF_LONG,          // 0: two-pass SWT for banks of more than 20 taps instead of the run-time-tap-count fused level kernels
+    KN_F64_TAIL,           // double-precision 2-D: levels of at most this many pixels per side run in ONE launch per direction (0 = off)
+    KN_EXP0,               // experimental knobs of the round (meaning: see the code that reads them)
+    KN_EXP1,
+    KN_EXP2,
+    KN_EXP3,
     KN_COUNT
 };
 int knob(KnobId id);
+// The hand-counted `s_waitcnt vmcnt(N)` pipelines (stream_dev.hpp) rely on undocumented ordering of a wave's loads and stores, EXEC = 0
+// stores included: verified ONCE per device, on the first use of such a kernel (selfcheck.hip; ~10 ms), cached; false = the check found
+// stale registers there -> callers take the compiler-counted kernels.
+bool counted_waits_ok();
 void stat_casc_spec(int inverse);  // (test statistics: a wave-program kernel was launched)
 int knob_set(const char* name, int value);  // PDWT_OK / PDWT_EINVAL (unknown name)
 int knob_get(const char* name, int* value);

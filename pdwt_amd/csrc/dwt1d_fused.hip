@@ -16,6 +16,7 @@
 // (aligned 16-byte LDS reads), so an input sample is read from LDS ~1.4x instead of hlen/2 times.
 // Tap order / one FMA per tap as in the reference kernels (src/separable.cu:112-127, 305-326): the
 // results are bit-identical to the per-level kernels and to the CPU oracle.
+#include <algorithm>
 #include <type_traits>
 
 #include "common.hpp"
@@ -239,6 +240,127 @@ __global__ __launch_bounds__(256) void k_fwd1d_fused(const T* __restrict__ in, B
             n = no;
         }
     }
+}
+
+// -------------------------------------------------------------------------------------------------
+// forward, ONE row buffer ("in place"): rows whose two-buffer footprint leaves room for a single workgroup per CU -- double precision at
+// 8192 samples: 64 KiB row + 32 KiB level-1 approximation -- ran the per-level kernels (3.75x the traffic: 0.81 ms for the C4 shape in
+// double against 0.22 in float).  Here a level's approximation outputs wait in REGISTERS (at most MAXIT items per thread) until every
+// thread has read its windows, then overwrite the front of the same buffer: 66 KiB, two workgroups per CU, and the next row's 16 chunks
+// per thread are prefetched during the row (KPRE).  Same item arithmetic as k_fwd1d_fused: bit-identical.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int HLEN, int MAXIT, int KPRE>
+__global__ __launch_bounds__(256, 2) void k_fwd1d_fused_ip(const T* __restrict__ in, Bands1D<T> b, int Nr, Taps2<T> f)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = Fwd1DGeom<T, HLEN>;
+    using V = typename Vec16<T>::type;
+    constexpr int NV = G::NV, PO = G::PO, C = G::C, CA = G::CA, WL = G::WL, HL = G::HL, HR = G::HR;
+    constexpr int HLS = HL / NV;
+    const int Nc = b.n[0];
+    V* const B0 = reinterpret_cast<V*>(smem);
+    auto elem = [](V* B, int e) -> T& {
+        const int le = e + HL;
+        return reinterpret_cast<T*>(B + swz(le / NV))[le % NV];
+    };
+    auto fill_halo = [&](V* B, int n) {
+        for (int k = threadIdx.x; k < HL + HR; k += 256) {
+            const int idx = k < HL ? k - HL : n + (k - HL);
+            elem(B, idx) = elem(B, wrap_ext(idx, n));
+        }
+    };
+    const int nchunks = Nc / NV;  // (host: Nc % NV == 0, aligned rows, nchunks <= KPRE * 256)
+    V pre[KPRE];
+    // (the lane index is laundered per row: otherwise hipcc hoists the KPRE clamped 64-bit addresses out of the row loop and keeps -- spills --
+    // 2 x KPRE registers of them)
+#define PDWT_ISSUE_ROW_IP(ROW)                                                                                 \
+    {                                                                                                          \
+        const V* src_ = reinterpret_cast<const V*>(in + (size_t)(ROW) * (size_t)Nc);                            \
+        int tx_ = threadIdx.x;                                                                                 \
+        asm volatile("" : "+v"(tx_));                                                                          \
+        sfor<KPRE>([&](auto K_) {                                                                              \
+            constexpr int k_ = decltype(K_)::value;                                                            \
+            pre[k_] = src_[min(tx_ + 256 * k_, nchunks - 1)];                                                  \
+        });                                                                                                    \
+    }
+    size_t row = blockIdx.x;
+    PDWT_ISSUE_ROW_IP(row < (size_t)Nr ? row : (size_t)Nr - 1)
+    for (; row < (size_t)Nr; row += gridDim.x) {
+        sfor<KPRE>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            if (threadIdx.x + 256 * k < nchunks) B0[swz(HLS + threadIdx.x + 256 * k)] = pre[k];
+        });
+        {
+            const size_t nr = row + gridDim.x;
+            PDWT_ISSUE_ROW_IP(nr < (size_t)Nr ? nr : (size_t)Nr - 1)  // lands while this row is transformed
+        }
+        lds_barrier();
+        fill_halo(B0, Nc);
+        lds_barrier();
+        int n = Nc;
+        for (int lev = 1; lev <= b.nlev; lev++) {
+            const int no = (n + 1) >> 1;
+            T* gd = b.p[lev] + row * (size_t)no;
+            T* ga = b.p[0] + row * (size_t)no;
+            const bool last = lev == b.nlev;
+            const bool vec_ok = ((no % NV) == 0) && ((reinterpret_cast<uintptr_t>(gd) & 15) == 0) && ((reinterpret_cast<uintptr_t>(ga) & 15) == 0);
+            const int items = (no + PO - 1) / PO;  // (host: items <= MAXIT * 256 at level 1, hence at every level)
+            V keep[MAXIT];
+            sfor<MAXIT>([&](auto Kk) {
+                constexpr int kk = decltype(Kk)::value;
+                const int it = threadIdx.x + 256 * kk;
+                if (it < items) {
+                    const int i0 = it * PO;
+                    T w[WL];
+#pragma unroll
+                    for (int k = 0; k < WL / NV; k++) {
+                        const V t = B0[swz(2 * it + k)];
+#pragma unroll
+                        for (int q = 0; q < NV; q++) w[k * NV + q] = t[q];
+                    }
+                    V vlo, vhi;
+#pragma unroll
+                    for (int q = 0; q < PO; q++) {
+                        T l = 0, h = 0;
+#pragma unroll
+                        for (int j = 0; j < HLEN; j++) {
+                            const T v = w[CA - C + 2 * q + j];
+                            l = fma_t(v, f.a[HLEN - 1 - j], l);
+                            h = fma_t(v, f.b[HLEN - 1 - j], h);
+                        }
+                        vlo[q] = l;
+                        vhi[q] = h;
+                    }
+                    if (vec_ok) {
+                        *reinterpret_cast<V*>(gd + i0) = vhi;
+                        if (last) *reinterpret_cast<V*>(ga + i0) = vlo;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < PO; q++)
+                            if (i0 + q < no) {
+                                gd[i0 + q] = vhi[q];
+                                if (last) ga[i0 + q] = vlo[q];
+                            }
+                    }
+                    keep[kk] = vlo;
+                }
+                // (one item at a time: interleaved, the windows of several items push the kernel past 256 registers = one workgroup per CU)
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            lds_barrier();  // every window of this level has been read
+            if (last) break;
+            sfor<MAXIT>([&](auto Kk) {
+                constexpr int kk = decltype(Kk)::value;
+                const int it = threadIdx.x + 256 * kk;
+                if (it < items) B0[swz(HLS + it)] = keep[kk];  // (a partial last item spills into halo cells, refilled below)
+            });
+            lds_barrier();
+            fill_halo(B0, no);
+            lds_barrier();
+            n = no;
+        }
+    }
+#undef PDWT_ISSUE_ROW_IP
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -489,6 +611,98 @@ __global__ __launch_bounds__(256) void k_inv1d_fused_pf(T* __restrict__ out_img,
 #undef PDWT_ISSUE_BANDS
 }
 
+// -------------------------------------------------------------------------------------------------
+// inverse, TWO buffers instead of three (cf. k_fwd1d_fused_ip): a level's outputs wait in registers until every thread has read its
+// windows of `a` and `sd`, then overwrite `a`.  Double precision at 8192 samples: 66 KiB instead of 99 -> two workgroups per CU; the
+// prefetch slots are CAP times those of k_inv1d_fused_pf (CAP = 2: D1 8, D2 4, the others 2 chunks per thread).
+// -------------------------------------------------------------------------------------------------
+template <int CAP> __host__ __device__ constexpr int inv_cap_x(int lev) { return CAP * inv_cap(lev); }
+template <int CAP> __host__ __device__ constexpr int inv_slot0_x(int lev) { return CAP * inv_slot0(lev); }
+
+template <typename T, int HLEN, int MAXIT, int CAP>
+__global__ __launch_bounds__(256, 2) void k_inv1d_fused_ip(T* __restrict__ out_img, Bands1D<T> b, int Nr, Taps2<T> f)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = Inv1DGeom<T, HLEN>;
+    using V = typename Vec16<T>::type;
+    constexpr int NV = G::NV, PO = G::PO, HL = G::HL, HR = G::HR;
+    const int Nc = b.n[0];
+    const int L = b.nlev;
+    const int be = G::buf_elems(b.n[1]);
+    T* const a = reinterpret_cast<T*>(smem) + HL;
+    T* const sd = a + be;
+
+    V pre[CAP * kInvSlots];
+#define PDWT_ISSUE_BANDS_IP(ROW)                                                                       \
+    sfor<kInvMaxLev + 1>([&](auto LV_) {                                                               \
+        constexpr int lv_ = decltype(LV_)::value;                                                      \
+        const int lc_ = lv_ == 0 ? 0 : (lv_ < L ? lv_ : L);                                            \
+        const int n_ = lv_ == 0 ? b.n[L] : b.n[lc_];                                                   \
+        const V* src_ = reinterpret_cast<const V*>(b.p[lc_] + (size_t)(ROW) * (size_t)n_);            \
+        sfor<inv_cap_x<CAP>(lv_)>([&](auto K_) {                                                       \
+            constexpr int k_ = decltype(K_)::value;                                                    \
+            pre[inv_slot0_x<CAP>(lv_) + k_] = src_[min((int)threadIdx.x + 256 * k_, n_ / NV - 1)];     \
+        });                                                                                            \
+    });
+
+    size_t row = blockIdx.x;
+    PDWT_ISSUE_BANDS_IP(row < (size_t)Nr ? row : (size_t)Nr - 1)
+
+    for (; row < (size_t)Nr; row += gridDim.x) {
+        sfor<inv_cap_x<CAP>(0)>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            if ((int)threadIdx.x + 256 * k < b.n[L] / NV) reinterpret_cast<V*>(a)[threadIdx.x + 256 * k] = pre[inv_slot0_x<CAP>(0) + k];
+        });
+        sfor<kInvMaxLev>([&](auto LI_) {
+            constexpr int lev = kInvMaxLev - decltype(LI_)::value;  // 6, 5, ..., 1
+            if (lev == 1 || lev <= L) {
+                const int nin = b.n[lev], nout = b.n[lev - 1];
+                sfor<inv_cap_x<CAP>(lev)>([&](auto K_) {
+                    constexpr int k = decltype(K_)::value;
+                    if ((int)threadIdx.x + 256 * k < nin / NV) reinterpret_cast<V*>(sd)[threadIdx.x + 256 * k] = pre[inv_slot0_x<CAP>(lev) + k];
+                });
+                if constexpr (lev == 1) {
+                    const size_t nr = row + gridDim.x;
+                    PDWT_ISSUE_BANDS_IP(nr < (size_t)Nr ? nr : (size_t)Nr - 1)
+                }
+                lds_barrier();
+                if (lev == L) fill_halo<T, false>(a, nin, HL, HR);
+                fill_halo<T, false>(sd, nin, HL, HR);
+                lds_barrier();
+                const int items = (nout + PO - 1) / PO;
+                if constexpr (lev == 1) {  // the image row: straight to HBM
+                    T* g = out_img + row * (size_t)Nc;
+                    const bool vec_ok = (nout % NV) == 0;
+                    for (int it = threadIdx.x; it < items; it += 256) {
+                        V res[2];
+                        inv1d_item<T, HLEN>(a, sd, it, f, res);
+                        inv1d_store<T, NV, V>(g, it * PO, nout, vec_ok, res);
+                    }
+                    lds_barrier();  // (the next row's A_L overwrites `a`)
+                } else {
+                    V keep[MAXIT][2];  // (host: items <= MAXIT * 256 at level 2, hence at every parked level)
+                    sfor<MAXIT>([&](auto Kk) {
+                        constexpr int kk = decltype(Kk)::value;
+                        const int it = threadIdx.x + 256 * kk;
+                        if (it < items) inv1d_item<T, HLEN>(a, sd, it, f, keep[kk]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    lds_barrier();  // every window of `a` and `sd` has been read
+                    sfor<MAXIT>([&](auto Kk) {
+                        constexpr int kk = decltype(Kk)::value;
+                        const int it = threadIdx.x + 256 * kk;
+                        if (it < items) inv1d_store<T, NV, V>(a, it * PO, nout + HR - PO, true, keep[kk]);
+                    });
+                    lds_barrier();
+                    fill_halo<T, false>(a, nout, HL, HR);
+                    // (the barrier after the next level's detail staging publishes the halo)
+                }
+            }
+        });
+    }
+#undef PDWT_ISSUE_BANDS_IP
+}
+
 // =================================================================================================
 // host side
 // =================================================================================================
@@ -529,8 +743,28 @@ static int launch_fwd(const T* in, T** c, const pdwt_info& w, const Taps2<T>& f)
     using G = Fwd1DGeom<T, HLEN>;
     // a single level never writes the second buffer (its approximation goes straight to HBM)
     const size_t lds = ((size_t)G::buf_elems(w.Nc) + (w.nlevels > 1 ? (size_t)G::buf_elems(b.n[1]) : 0)) * sizeof(T);
-    if (lds > lds_budget_1d()) return 1;
     constexpr int NVh = Vec16<T>::N;
+    if (lds > lds_budget_1d()) {
+        // the one-buffer form (double precision only: float rows of that size are a wash, see lds_budget_1d) when IT fits the budget
+        if constexpr (sizeof(T) == 8) {
+            constexpr int MAXIT = 8, KPRE = 16;
+            const size_t lds1 = (size_t)G::buf_elems(w.Nc) * sizeof(T);
+            const int items1 = (b.n[1] + G::PO - 1) / G::PO;
+            // (banks of more than 20 taps: the window of an item no longer fits next to the prefetch registers -- scratch spills -- per-level kernels)
+            if (HLEN <= 20 && knob(KN_DWT1D_F64) == 1 && w.nlevels > 1 && lds1 <= lds_budget_1d() && items1 <= MAXIT * 256 && (w.Nc % NVh) == 0 && ((uintptr_t)in & 15) == 0 &&
+                (w.Nc / NVh) <= KPRE * 256) {
+                auto k = k_fwd1d_fused_ip<T, HLEN, MAXIT, KPRE>;
+                if (set_lds(k, lds1) != PDWT_OK) return PDWT_EHIP;
+                const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / (lds1 + 512))));
+                const int grid = w.Nr < 256 * per_cu ? w.Nr : 256 * per_cu;
+                KTimer kt(K_ANA_ROWS, true);
+                PDWT_LAUNCH_KT(kt, k, dim3(grid), dim3(256), lds1, in, b, w.Nr, f);
+                PDWT_CHECK_LAUNCH();
+                return PDWT_OK;
+            }
+        }
+        return 1;
+    }
     const bool pre = (w.Nc % NVh) == 0 && ((uintptr_t)in & 15) == 0 && (w.Nc / NVh) <= kPre1D * 256;
     auto k = pre ? k_fwd1d_fused<T, HLEN, true> : k_fwd1d_fused<T, HLEN, false>;
     if (set_lds(k, lds) != PDWT_OK) return PDWT_EHIP;
@@ -551,8 +785,30 @@ static int launch_inv(T* out, T** c, const pdwt_info& w, const Taps2<T>& f)
     using G = Inv1DGeom<T, HLEN>;
     // a single level writes the image row straight to HBM: no output buffer in LDS
     const size_t lds = (w.nlevels > 1 ? 3 : 2) * (size_t)G::buf_elems(b.n[1]) * sizeof(T);
-    if (lds > lds_budget_1d()) return 1;
     constexpr int NVh = Vec16<T>::N;
+    if (lds > lds_budget_1d()) {
+        if constexpr (sizeof(T) == 8) {
+            constexpr int MAXIT = 4, CAP = 2;
+            const size_t lds2 = 2 * (size_t)G::buf_elems(b.n[1]) * sizeof(T);
+            bool ok = knob(KN_DWT1D_F64) == 1 && w.nlevels > 1 && w.nlevels <= kInvMaxLev && lds2 <= lds_budget_1d() && (w.Nc % NVh) == 0 && ((uintptr_t)out & 15) == 0 &&
+                      (b.n[1] + G::PO - 1) / G::PO <= MAXIT * 256;
+            for (int l = 0; l <= w.nlevels && ok; l++) {
+                const int n = l == 0 ? b.n[w.nlevels] : b.n[l];
+                ok = (n % NVh) == 0 && n / NVh <= 256 * inv_cap_x<CAP>(l) && ((uintptr_t)b.p[l] & 15) == 0 && n >= NVh;
+            }
+            if (ok) {
+                auto k = k_inv1d_fused_ip<T, HLEN, MAXIT, CAP>;
+                if (set_lds(k, lds2) != PDWT_OK) return PDWT_EHIP;
+                const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / (lds2 + 512))));
+                const int grid = w.Nr < 256 * per_cu ? w.Nr : 256 * per_cu;
+                KTimer kt(K_SYN_ROWS, true);
+                PDWT_LAUNCH_KT(kt, k, dim3(grid), dim3(256), lds2, out, b, w.Nr, f);
+                PDWT_CHECK_LAUNCH();
+                return PDWT_OK;
+            }
+        }
+        return 1;
+    }
     bool pf = w.nlevels <= kInvMaxLev && (w.Nc % NVh) == 0 && ((uintptr_t)out & 15) == 0;
     for (int l = 0; l <= w.nlevels && pf; l++) {
         const int n = l == 0 ? b.n[w.nlevels] : b.n[l];
@@ -574,7 +830,9 @@ static int launch_inv(T* out, T** c, const pdwt_info& w, const Taps2<T>& f)
     return PDWT_OK;
 }
 
+#ifndef PDWT_1D_HLENS  // (a diagnostic build may restrict the instantiated lengths)
 #define PDWT_1D_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) X(34) X(36) X(38) X(40)
+#endif
 
 template <typename T>
 int fwd1d_fused(const T* in, T** c, const pdwt_info& w, const Taps2<T>& f)

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void k_inv2d_stream(const float* __restrict__ 
 // =================================================================================================
 // host dispatch
 // =================================================================================================
-bool stream_enabled() { return knob(KN_STREAM) == 1; }
+bool stream_enabled() { return knob(KN_STREAM) == 1 && counted_waits_ok(); }  // (also gates the cascade kernels: dwt_casc*.hip)
 
 // rows of output (forward) / coefficient rows (inverse) per wave: enough waves to fill the chip
 // (256 CUs x 4 SIMDs x a few waves), chunks tall enough to amortise the halo rows

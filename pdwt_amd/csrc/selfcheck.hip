@@ -4,9 +4,15 @@
 //   * a store issued with EXEC = 0 (the loop forms of the cascade kernels store rows a wave does not own that way) still takes its
 //     place in that order and in the count.
 // Neither is documented; both were established with tools/probes/vmcnt_order.hip on gfx950 (MI355X, ROCm 7.2).  pdwt_selfcheck_vmcnt_order()
-// runs a compact form of that probe on the current device -- deployments on a new stepping / firmware call it once (tests/ does, -m gpu):
-// a non-zero count of stale registers means the counted waits under-count there and `PDWT_CASC=0 PDWT_STREAM=0` (compiler-counted
-// kernels) is the safe configuration.  The build itself refuses any other architecture (stream_dev.hpp).
+// runs a compact form of that probe on the current device: a non-zero count of stale registers means the counted waits under-count
+// there.  The PRODUCT runs it by itself: counted_waits_ok() -- asked by every dispatcher of a hand-counted kernel (dwt_stream.hip:
+// stream_enabled(), which also gates the cascade kernels; the fused SWT levels) -- runs it once per device on first use, caches the
+// verdict and, when stale registers were seen, sends every such geometry to the compiler-counted kernels (LDS-tiled / two-pass) with
+// one warning on stderr.  PDWT_SELFCHECK=0 skips the check (the build itself refuses any other architecture, stream_dev.hpp).
+#include <atomic>
+#include <cstdio>
+#include <mutex>
+
 #include "common.hpp"
 
 namespace pdwt {
@@ -56,9 +62,41 @@ __global__ __launch_bounds__(256) void k_sc_order(const float* __restrict__ tab,
 
 using namespace pdwt;
 
-extern "C" long long pdwt_selfcheck_vmcnt_order(void)
+namespace pdwt {
+static long long selfcheck_run(size_t table_mib, size_t sink_mib);
+bool counted_waits_ok()
 {
-    const size_t n4 = ((size_t)256 << 20) / 16, sink4 = ((size_t)512 << 20) / 16;  // 256 MiB table (loads miss the caches), 512 MiB store target
+    static std::atomic<int> verdict[64];  // 0 = not yet asked, 1 = ok, 2 = stale registers seen
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    int v = verdict[dev].load(std::memory_order_acquire);
+    if (v) return v == 1;
+    if (knob(KN_SELFCHECK) == 0) return true;
+    // (a check needs allocations and a host read-back: not inside a stream capture -- that call keeps the default, the next one outside decides)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream(), &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return true;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    v = verdict[dev].load(std::memory_order_acquire);
+    if (v) return v == 1;
+    long long bad = selfcheck_run(256, 256);
+    if (bad < 0) bad = selfcheck_run(64, 64);  // (no memory for the full-size probe)
+    if (bad > 0)
+        fprintf(stderr, "pdwt: device %d retires loads and stores out of the order the hand-counted waits assume (%lld stale registers in the self-check): "
+                        "using the compiler-counted kernels\n", dev, bad);
+    verdict[dev].store(bad > 0 ? 2 : 1, std::memory_order_release);  // (a probe that could not run at all leaves the build guard's answer)
+    return bad <= 0;
+}
+}  // namespace pdwt
+
+extern "C" long long pdwt_selfcheck_vmcnt_order(void) { return pdwt::selfcheck_run(256, 512); }  // 256 MiB table (loads miss the caches), 512 MiB store target
+
+static long long pdwt::selfcheck_run(size_t table_mib, size_t sink_mib)
+{
+    const size_t n4 = (table_mib << 20) / 16, sink4 = (sink_mib << 20) / 16;
     float* tab = (float*)pdwt_malloc(n4 * 16);
     float* sink = (float*)pdwt_malloc(sink4 * 16);
     unsigned long long* bad = (unsigned long long*)pdwt_malloc(8);

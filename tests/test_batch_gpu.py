@@ -175,6 +175,14 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["other_configs"] is None
     assert d["sanity"]["norm1_ranks"] == 2 and d["sanity"]["norm1_allreduce_rel_err"] <= 1e-12 and d["roundtrip_max_rel_err"] <= 1e-5
+    # round 5: the N > 1 line also carries the two HBM-streaming workloads (16 distinct images per GPU through the batched entry, the C4
+    # shard), the size of the collective group taken from the communicator, and per-rank clock / power means
+    assert d["value_streaming"] > 0 and d["ms_per_image_pair_streaming"] > 0 and d["c4_value"] > 0 and d["c4_ms_per_step"] > 0
+    sr = d["streaming_runs"]
+    assert sr["c2_batch"]["value"] == d["value_streaming"] and sr["c4"]["value"] == d["c4_value"]
+    assert sr["c2_batch"]["sanity"]["norm1_ranks"] == 2 and sr["c4"]["sanity"]["roundtrip_max_rel_err"] <= 1e-5
+    assert d["collective"] == {"backend": "gloo", "ranks": 2} and d["rccl_ranks"] is None  # (gloo here; the driver's runs: "nccl" = RCCL)
+    assert len(d["per_rank"]["sclk_mhz_mean"]) == 2 and len(d["per_rank"]["socket_w_mean"]) == 2
 
 
 @pytest.mark.parametrize("exe,shards", [("batch_demo", 3), ("batch_demod", 2), ("batch_demo", 8), ("batch_demo", 1), ("batch_demod", 1)])

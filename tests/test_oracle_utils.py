@@ -112,3 +112,23 @@ def test_oracle_nonseparable_is_separable_with_h_and_v_exchanged():
             assert band_err(O.get_coeff(3 * l + 3), d["band%d" % (3 * l + 3)]) <= 1e-10
         O.inverse()
         assert band_err(O.get_image(), d["recon"]) <= 1e-10
+
+
+NSEP_CASES = ["nsep_dec_h6_48x64_L2", "nsep_dec_h4_33x47_L2_odd", "nsep_dec_h5_40x56_L1", "nsep_swt_h4_32x48_L2", "nsep_swt_h5_40x56_L2"]
+
+
+@pytest.mark.parametrize("name", NSEP_CASES)
+def test_oracle_custom_nonseparable_kernels_vs_independent_direct_sums(name):
+    """Four arbitrary hlen x hlen kernels (src/nonseparable.cu:114-225, 304-401): the oracle's sample-by-sample restatement against the
+    array-wise float64 evaluation of the same defining sums in tests/golden/make_golden_nonsep.py (no pywt counterpart exists)."""
+    d = load_golden(name)
+    swt, L = int(d["swt"]), d["levels"]
+    O = orc.OracleWavelets(d["input"], "db2", L, do_separable=0, do_swt=swt)
+    assert O.info.nlevels == L
+    assert O.set_filters_forward_nonseparable("custom2d", *[d["kf%d" % q] for q in range(4)]) == 0
+    assert O.set_filters_inverse_nonseparable(*[d["ki%d" % q] for q in range(4)]) == 0
+    O.forward()
+    for k in range(d["nbands"]):
+        assert band_err(O.get_coeff(k), d["band%d" % k]) <= 1e-12, (name, k)
+    O.inverse()
+    assert band_err(O.get_image(), d["recon"]) <= 1e-12, name

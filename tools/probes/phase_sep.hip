@@ -142,6 +142,8 @@ static float timeit(F f, int reps)
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     f();
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
     std::vector<float> t;
     for (int i = 0; i < reps; i++) {
         CK(hipEventRecord(e0));
@@ -160,7 +162,9 @@ static float timeit(F f, int reps)
 
 int main(int argc, char** argv)
 {
+    setvbuf(stdout, NULL, _IONBF, 0);
     const double gib = argc > 1 ? atof(argv[1]) : 2.0;
+    const int only = argc > 2 ? atoi(argv[2]) : -1;  // (debug: 0 = reference lines only, 1 = phase kernels only)
     hipDeviceProp_t pr;
     CK(hipGetDeviceProperties(&pr, 0));
     const int ncu = pr.multiProcessorCount;
@@ -185,7 +189,7 @@ int main(int argc, char** argv)
         const size_t n4 = bytes / 16;
         const int reps = 7;
         printf("\n## buffer %zu MiB (x2: source + destination)\n", bytes >> 20);
-        {
+        if (only != 1) {
             const int grid = ncu * 8;
             const float r0 = timeit([&] { k_read<false><<<grid, 256>>>(a, sink, n4); }, reps);
             const float r1 = timeit([&] { k_read<true><<<grid, 256>>>(a, sink, n4); }, reps);
@@ -196,6 +200,7 @@ int main(int argc, char** argv)
                    bytes / r1 / 1e6, bytes / w0 / 1e6, 2.0 * bytes / c0 / 1e6, 2.0 * bytes / c1 / 1e6, 2.0 * bytes / (std::min(r0, r1) + w0) / 1e6);
         }
         printf("| K per workgroup | per phase, chip | local | local nt | chip (drain) | chip nt (drain) | chip (no drain) | chip nt (no drain) |\n|---|---|---|---|---|---|---|---|\n");
+        if (only == 0) continue;
         for (int kkb : {4, 8, 16, 32, 64, 128}) {
             const int kel = kkb * 1024 / 16;
             const int grid = ncu;  // one workgroup of 1024 threads per CU: every workgroup is resident (the grid barrier needs that)
