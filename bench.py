@@ -802,7 +802,7 @@ def main():
         }
         # the HBM-streaming throughputs next to the cache-resident headline, at every N: whole-job Mpixels/s of 16 distinct images per GPU
         # through the batched entry, and whole-job Msamples/s of the C4 shards (N = 1: the same numbers as other_configs.c2_batch / .c4)
-        src = streaming if world > 1 else (others or {})
+        src = (streaming if world > 1 else others) or {}
         cbs, c4s = src.get("c2_batch") or {}, src.get("c4") or {}
         line["value_streaming"] = cbs.get("value")
         line["ms_per_image_pair_streaming"] = cbs.get("ms_per_image_pair")

@@ -28,16 +28,16 @@
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// (compiler-visible loads: an inline-asm load "defines" its register at once as far as hipcc knows -- it then reuses the destination, e.g. as
+// the address register of the next load, while the load is still in flight: a first version of this file faulted that way)
 template <bool NT>
 __device__ __forceinline__ v4f ld(const v4f* p)
 {
-    v4f d;
-    if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(d) : "v"(p) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
-    return d;
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
 }
 __device__ __forceinline__ void st(v4f* p, v4f d) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(d) : "memory"); }
-__device__ __forceinline__ void waitall() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void waitall() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }  // (stores only: loads are the compiler's)
 
 // grid barrier: the counter only grows; barrier number b (1-based) is passed when it has reached b * G
 __device__ __forceinline__ void grid_barrier(unsigned* cnt, unsigned target)
