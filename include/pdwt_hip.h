@@ -117,6 +117,13 @@ void* pdwt_batch2d_create_f32(int nimg, float* const* d_images, float** const* d
 int pdwt_batch2d_forward_f32(void* batch, const pdwt_filters_f32* f);
 int pdwt_batch2d_inverse_f32(void* batch, const pdwt_filters_f32* f);
 void pdwt_batch2d_destroy(void* batch);
+/* the same in double precision (libpdwtd): every level of all images in one launch of the fused double-precision level kernels; any even
+ * bank of up to 40 taps, odd sizes included, every level at least 16 rows and the (padded) bank length in either direction; NULL otherwise.
+ * The object of the _f64 create goes to the _f64 forward / inverse / destroy. */
+void* pdwt_batch2d_create_f64(int nimg, double* const* d_images, double** const* d_coeffs, double* const* d_tmps, pdwt_info info);
+int pdwt_batch2d_forward_f64(void* batch, const pdwt_filters_f64* f);
+int pdwt_batch2d_inverse_f64(void* batch, const pdwt_filters_f64* f);
+void pdwt_batch2d_destroy_f64(void* batch);
 
 /* In-kernel clock probe of the fused level kernels of dwt_lds.hip (the C5 kernels): while enabled, workgroup 0 of every such
  * launch records the shader-clock counter and the 100 MHz real-time counter at its start and end.  slot = direction * 8 + size

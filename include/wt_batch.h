@@ -140,8 +140,23 @@ class WaveletsBatch {
  * (pdwt_batch2d_*, include/pdwt_hip.h) when the geometry allows -- small images are launch-bound, six launches per pair whatever
  * the size -- otherwise image after image.  Each image is an ordinary `Wavelets` instance (it owns image, bands and scratch:
  * img[b]->get_coeff(...), soft_threshold(...) etc. work as usual between forward() and inverse()); results are those of the
- * per-image transforms bit for bit.  Float build only for the one-launch form (libpdwt); libpdwtd loops over the images.
+ * per-image transforms bit for bit.  Both builds (round 5: libpdwtd batches through the fused double-precision level kernels).
  */
+#ifdef DOUBLEPRECISION
+#define WB_FILTERS pdwt_filters_f64
+#define WB_COMPUTE_FILTERS pdwt_compute_filters_separable_f64
+#define WB_CREATE pdwt_batch2d_create_f64
+#define WB_FORWARD pdwt_batch2d_forward_f64
+#define WB_INVERSE pdwt_batch2d_inverse_f64
+#define WB_DESTROY pdwt_batch2d_destroy_f64
+#else
+#define WB_FILTERS pdwt_filters_f32
+#define WB_COMPUTE_FILTERS pdwt_compute_filters_separable_f32
+#define WB_CREATE pdwt_batch2d_create_f32
+#define WB_FORWARD pdwt_batch2d_forward_f32
+#define WB_INVERSE pdwt_batch2d_inverse_f32
+#define WB_DESTROY pdwt_batch2d_destroy
+#endif
 class WaveletsImages {
   public:
     std::vector<Wavelets*> img;
@@ -157,10 +172,9 @@ class WaveletsImages {
             img.back()->set_norm_cache(0);
             if (img.back()->state != W_CREATION_ERROR) (void)img.back()->coeff_int_ptr(0);
         }
-#ifndef DOUBLEPRECISION
         if (ok()) {
-            std::vector<float*> di, dt;
-            std::vector<float**> dc;
+            std::vector<DTYPE*> di, dt;
+            std::vector<DTYPE**> dc;
             for (int b = 0; b < B; b++) {
                 di.push_back(img[b]->d_image);
                 dc.push_back(img[b]->d_coeffs);
@@ -168,14 +182,12 @@ class WaveletsImages {
             }
             const w_info w = img[0]->winfos;
             pdwt_info info = {w.ndims, w.Nr, w.Nc, w.nlevels, w.do_swt, w.hlen};
-            if (pdwt_compute_filters_separable_f32(wname, 0, &bank_) == w.hlen)
-                batch_ = pdwt_batch2d_create_f32(B, di.data(), dc.data(), dt.data(), info);
+            if (WB_COMPUTE_FILTERS(wname, 0, &bank_) == w.hlen) batch_ = WB_CREATE(B, di.data(), dc.data(), dt.data(), info);
         }
-#endif
     }
     ~WaveletsImages()
     {
-        if (batch_) pdwt_batch2d_destroy(batch_);
+        if (batch_) WB_DESTROY(batch_);
         for (size_t b = 0; b < img.size(); b++) delete img[b];
     }
     bool ok() const
@@ -194,24 +206,20 @@ class WaveletsImages {
     }
     void forward()
     {
-#ifndef DOUBLEPRECISION
-        if (batch_ && named_bank() && pdwt_batch2d_forward_f32(batch_, &bank_) == 0) {
+        if (batch_ && named_bank() && WB_FORWARD(batch_, &bank_) == 0) {
             for (size_t b = 0; b < img.size(); b++) img[b]->state = W_FORWARD;
             return;
         }
-#endif
         for (size_t b = 0; b < img.size(); b++) img[b]->forward();
     }
     void inverse()
     {
-#ifndef DOUBLEPRECISION
         bool all_fwd = true;
         for (size_t b = 0; b < img.size(); b++) all_fwd = all_fwd && img[b]->state != W_INVERSE && img[b]->state != W_CREATION_ERROR;
-        if (batch_ && all_fwd && named_bank() && pdwt_batch2d_inverse_f32(batch_, &bank_) == 0) {
+        if (batch_ && all_fwd && named_bank() && WB_INVERSE(batch_, &bank_) == 0) {
             for (size_t b = 0; b < img.size(); b++) img[b]->state = W_INVERSE;
             return;
         }
-#endif
         for (size_t b = 0; b < img.size(); b++) img[b]->inverse();
     }
     /* all images, stacked; returns the element count */
@@ -224,9 +232,7 @@ class WaveletsImages {
 
   private:
     void* batch_;
-#ifndef DOUBLEPRECISION
-    pdwt_filters_f32 bank_;
-#endif
+    WB_FILTERS bank_;
     WaveletsImages(const WaveletsImages&);
     WaveletsImages& operator=(const WaveletsImages&);
 };

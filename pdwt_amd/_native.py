@@ -42,6 +42,7 @@ PLAIN_SYMBOLS = ["pdwt_device_count", "pdwt_set_device", "pdwt_get_device", "pdw
                  "pdwt_kernel_count", "pdwt_graph_allowed", "pdwt_graph_capture_begin", "pdwt_graph_capture_end", "pdwt_graph_launch",
                  "pdwt_graph_destroy", "pdwt_num_wavelets", "pdwt_wavelet_name", "pdwt_num_bands", "pdwt_band_size", "pdwt_tmp_elems", "pdwt_debug_set", "pdwt_debug_get", "pdwt_clock_probe_enable", "pdwt_clock_probe_read", "pdwt_clock_probe_dump", "pdwt_probe_bandwidth", "pdwt_selfcheck_vmcnt_order", "pdwt_rccl_available", "pdwt_rccl_allreduce_sum_f64", "pdwt_sum_result_index", "pdwt_sum_spare_index",
                  "pdwt_batch2d_create_f32", "pdwt_batch2d_forward_f32", "pdwt_batch2d_inverse_f32", "pdwt_batch2d_destroy",
+                 "pdwt_batch2d_create_f64", "pdwt_batch2d_forward_f64", "pdwt_batch2d_inverse_f64", "pdwt_batch2d_destroy_f64",
                  "pdwt_sum_scratch_doubles", "pdwt_sum_scratch_read"]
 TYPED_SYMBOLS = (["compute_filters_separable", "create_coeffs_buffer", "free_coeffs_buffer", "copy_coeffs_buffer",
                   "soft_thresh", "soft_thresh_sum", "norm1", "norm1_as_double", "norm1_enqueue", "hard_thresh", "proj_linf", "shrink", "group_soft_thresh",
@@ -97,6 +98,11 @@ def hip():
     L.pdwt_batch2d_forward_f32.argtypes = [vp, vp]
     L.pdwt_batch2d_inverse_f32.argtypes = [vp, vp]
     L.pdwt_batch2d_destroy.argtypes = [vp]
+    L.pdwt_batch2d_create_f64.restype = vp
+    L.pdwt_batch2d_create_f64.argtypes = [ci, vp, vp, vp, Info]
+    L.pdwt_batch2d_forward_f64.argtypes = [vp, vp]
+    L.pdwt_batch2d_inverse_f64.argtypes = [vp, vp]
+    L.pdwt_batch2d_destroy_f64.argtypes = [vp]
     L.pdwt_clock_probe_dump.argtypes = [vp, ci]
     L.pdwt_sum_scratch_doubles.restype = sz
     L.pdwt_sum_result_index.restype = sz

@@ -1039,11 +1039,138 @@ static int batch2d_inverse(Batch2D* B, const pdwt_filters_f32* filt)
     return PDWT_OK;
 }
 
+// -------------------------------------------------------------------------------------------------
+// the same entry in double precision (round 5): every level of all images in one launch of the fused level kernels of dwt_lds.hip
+// (gridDim.y = image; five pointers per image and level in device-side tables built once).  Any even bank of up to 40 taps, any size
+// those kernels take (odd sizes included); the small levels -- which the single-image path hands to the latency-bound two-pass kernels --
+// run batched as well.  Same kernels, same arithmetic: bit-identical to the per-image transforms.
+// -------------------------------------------------------------------------------------------------
+struct Batch2D64 {
+    int nimg, dev;
+    pdwt_info w;
+    int lev_nr[34], lev_nc[34];
+    unsigned long long* d_fwd;  // [level][image][5]
+    unsigned long long* d_inv;  // [level][image][5]
+};
+
+static Batch2D64* batch2d_create_f64(int nimg, double* const* d_images, double** const* d_coeffs, double* const* d_tmps, pdwt_info w)
+{
+    if (nimg < 1 || nimg > 65535 || !d_images || !d_coeffs || !d_tmps || w.ndims != 2 || w.do_swt || w.nlevels < 1 || w.nlevels > 32) return nullptr;
+    if (force_twopass() || w.hlen < 2 || w.hlen > 40 || (w.hlen & 1) || knob(KN_F64_LDS) < 1) return nullptr;
+    Batch2D64* B = new (std::nothrow) Batch2D64();
+    if (!B) return nullptr;
+    B->nimg = nimg;
+    B->w = w;
+    B->d_fwd = B->d_inv = nullptr;
+    if (hipGetDevice(&B->dev) != hipSuccess) {
+        delete B;
+        return nullptr;
+    }
+    const int L = w.nlevels;
+    int nr = w.Nr, nc = w.Nc;
+    for (int lev = 0; lev <= L; lev++) {
+        B->lev_nr[lev] = nr;
+        B->lev_nc[lev] = nc;
+        if (lev < L && (nr < 16 || nr < ((w.hlen + 7) / 8) * 8 || nc < ((w.hlen + 7) / 8) * 8)) {  // (what fwd2d_lds_any / inv2d_lds_any ask of a level)
+            delete B;
+            return nullptr;
+        }
+        nr = div2(nr);
+        nc = div2(nc);
+    }
+    std::vector<unsigned long long> hf((size_t)L * nimg * 5), hi((size_t)L * nimg * 5);
+    for (int b = 0; b < nimg; b++) {
+        double* const* c = d_coeffs[b];
+        if (!d_images[b] || !c || !d_tmps[b]) {
+            delete B;
+            return nullptr;
+        }
+        Scratch<double> sc(d_tmps[b], w.Nr, w.Nc, 2);
+        const double* in = d_images[b];
+        int pp = 0;
+        for (int lev = 0; lev < L; lev++) {  // forward_separable's level loop
+            double* aout = (lev == L - 1) ? c[0] : sc.ping[pp];
+            unsigned long long* e = &hf[((size_t)lev * nimg + b) * 5];
+            e[0] = (unsigned long long)(uintptr_t)in;
+            e[1] = (unsigned long long)(uintptr_t)aout;
+            e[2] = (unsigned long long)(uintptr_t)c[3 * lev + 1];
+            e[3] = (unsigned long long)(uintptr_t)c[3 * lev + 2];
+            e[4] = (unsigned long long)(uintptr_t)c[3 * lev + 3];
+            if (!aout || !c[3 * lev + 1] || !c[3 * lev + 2] || !c[3 * lev + 3]) {
+                delete B;
+                return nullptr;
+            }
+            in = aout;
+            pp ^= 1;
+        }
+        const double* a = c[0];
+        pp = 0;
+        for (int i = L - 1; i >= 0; i--) {  // inverse_separable's level loop
+            double* out = (i == 0) ? d_images[b] : sc.ping[pp];
+            unsigned long long* e = &hi[((size_t)i * nimg + b) * 5];
+            e[0] = (unsigned long long)(uintptr_t)a;
+            e[1] = (unsigned long long)(uintptr_t)c[3 * i + 1];
+            e[2] = (unsigned long long)(uintptr_t)c[3 * i + 2];
+            e[3] = (unsigned long long)(uintptr_t)c[3 * i + 3];
+            e[4] = (unsigned long long)(uintptr_t)out;
+            a = out;
+            pp ^= 1;
+        }
+    }
+    const size_t bytes = hf.size() * sizeof(unsigned long long);
+    B->d_fwd = (unsigned long long*)pdwt_malloc(bytes);
+    B->d_inv = (unsigned long long*)pdwt_malloc(bytes);
+    if (!B->d_fwd || !B->d_inv || pdwt_memcpy_h2d(B->d_fwd, hf.data(), bytes) != PDWT_OK || pdwt_memcpy_h2d(B->d_inv, hi.data(), bytes) != PDWT_OK) {
+        pdwt_free(B->d_fwd);
+        pdwt_free(B->d_inv);
+        delete B;
+        return nullptr;
+    }
+    return B;
+}
+
+static int batch2d_forward_f64(Batch2D64* B, const pdwt_filters_f64* filt)
+{
+    if (!B || !filt || filt->hlen != B->w.hlen) return PDWT_EINVAL;
+    Batch2DDev on_dev(B->dev);
+    const Taps2<double> f = taps_fwd<double>(filt);
+    for (int lev = 0; lev < B->w.nlevels; lev++) {
+        const int rc = fwd2d_f64_lds_batch(B->d_fwd + (size_t)lev * B->nimg * 5, B->nimg, B->lev_nr[lev], B->lev_nc[lev], B->w.hlen, f);
+        if (rc != PDWT_OK) return rc < 0 ? rc : PDWT_EINVAL;
+    }
+    return PDWT_OK;
+}
+static int batch2d_inverse_f64(Batch2D64* B, const pdwt_filters_f64* filt)
+{
+    if (!B || !filt || filt->hlen != B->w.hlen) return PDWT_EINVAL;
+    Batch2DDev on_dev(B->dev);
+    const Taps2<double> f = taps_inv<double>(filt);
+    for (int i = B->w.nlevels - 1; i >= 0; i--) {
+        const int rc = inv2d_f64_lds_batch(B->d_inv + (size_t)i * B->nimg * 5, B->nimg, B->lev_nr[i + 1], B->lev_nc[i + 1], B->lev_nr[i], B->lev_nc[i], B->w.hlen, f);
+        if (rc != PDWT_OK) return rc < 0 ? rc : PDWT_EINVAL;
+    }
+    return PDWT_OK;
+}
+
 }  // namespace pdwt
 
 using namespace pdwt;
 
 extern "C" {
+void* pdwt_batch2d_create_f64(int nimg, double* const* d_images, double** const* d_coeffs, double* const* d_tmps, pdwt_info info)
+{
+    return batch2d_create_f64(nimg, d_images, d_coeffs, d_tmps, info);
+}
+int pdwt_batch2d_forward_f64(void* batch, const pdwt_filters_f64* f) { return batch2d_forward_f64((Batch2D64*)batch, f); }
+int pdwt_batch2d_inverse_f64(void* batch, const pdwt_filters_f64* f) { return batch2d_inverse_f64((Batch2D64*)batch, f); }
+void pdwt_batch2d_destroy_f64(void* batch)
+{
+    Batch2D64* B = (Batch2D64*)batch;
+    if (!B) return;
+    pdwt_free(B->d_fwd);
+    pdwt_free(B->d_inv);
+    delete B;
+}
 void* pdwt_batch2d_create_f32(int nimg, float* const* d_images, float** const* d_coeffs, float* const* d_tmps, pdwt_info info)
 {
     return batch2d_create(nimg, d_images, d_coeffs, d_tmps, info, info.hlen);

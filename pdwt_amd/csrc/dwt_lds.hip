@@ -164,9 +164,19 @@ struct F64Lds {
 template <typename T, int HLEN>
 __global__ __launch_bounds__(kNT, 2) void k_fwd2d_f64lds(TapTable<T> /*read through kernarg_taps()*/, const T* __restrict__ in,
                                                           T* __restrict__ cA, T* __restrict__ cH, T* __restrict__ cV,
-                                                          T* __restrict__ cD, int Nr, int Nc, int RO, int strips, unsigned long long* probe, int probe_all, int skew)
+                                                          T* __restrict__ cD, int Nr, int Nc, int RO, int strips, unsigned long long* probe, int probe_all, int skew,
+                                                          const void* tbl)
 {
     clock_probe_stamp(probe, 0, probe_all);
+    if (tbl) {  // batched launch (pdwt_batch2d_*_f64): this workgroup's image -- five pointers per image, read through the constant address space
+        typedef const unsigned long long __attribute__((address_space(4))) * tbl_t;
+        const tbl_t q = (tbl_t)(const unsigned long long*)tbl + 5 * (size_t)blockIdx.y;
+        in = (const T*)q[0];
+        cA = (T*)q[1];
+        cH = (T*)q[2];
+        cV = (T*)q[3];
+        cD = (T*)q[4];
+    }
     using G = F64Lds<T, HLEN>;
     using V2 = pair_t<T>;
     constexpr int ES = sizeof(T);
@@ -425,13 +435,15 @@ static int lds_skew(int strips, int chunks)
 // (C' = C + q, the original taps at positions q .. q+hlen-1); the extra terms are fma(x, 0, acc) = acc, so the result is the one
 // of the unpadded filter bit for bit (finite data).
 template <typename T, int HLEN>
-static int launch_fwd_f64lds(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, int nc, int hlen, const Taps2<T>& f)
+static int launch_fwd_f64lds(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, int nc, int hlen, const Taps2<T>& f, const void* d_tbl = nullptr,
+                             int nimg = 1)
 {
     using G = F64Lds<T, HLEN>;
     const int nr2 = div2(nr), nc2 = div2(nc);
     const int strips = idiv_up(nc2, kNCW);
     // two workgroups per CU when the level is large; one (steps run ~1.7x faster alone) when a chunk is mostly warm-up anyway
-    const int target = (long long)nr * nc >= 2048LL * 2048 ? knob(KN_F64_LDS_WGS) : knob(KN_F64_LDS_WGS) / 2;
+    // (a batch shares the target between its images: gridDim.y = image)
+    const int target = ((long long)nr * nc * nimg >= 2048LL * 2048 ? knob(KN_F64_LDS_WGS) : knob(KN_F64_LDS_WGS) / 2) / nimg;
     int chunks = std::max(1, target / strips);
     int RO = idiv_up(idiv_up(nr2, chunks), 4) * 4;
     RO = std::max(RO, 4 * knob(KN_F64_LDS_MINGROUPS));
@@ -459,8 +471,10 @@ static int launch_fwd_f64lds(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, in
     if (strips * chunks > kClockProbeAllBlocks) pall = 0;
     KTimer kt(K_FWD2D_F64);
     constexpr size_t lds = G::kLdsBytes;
-    hipLaunchKernelGGL((k_fwd2d_f64lds<T, HLEN>), dim3(strips * chunks), dim3(kNT), lds, stream(), tt, in, cA, cH, cV, cD, nr, nc, RO, strips,
-                       pall == 1 ? pbuf : clock_probe_slot(clock_probe_size_class(nr)), pall == 1 ? 1 : 0, lds_skew(strips, chunks));
+    if (nimg > 1) pall = 0;
+    hipLaunchKernelGGL((k_fwd2d_f64lds<T, HLEN>), dim3(strips * chunks, nimg), dim3(kNT), lds, stream(), tt, in, cA, cH, cV, cD, nr, nc, RO, strips,
+                       pall == 1 ? pbuf : (nimg > 1 ? nullptr : clock_probe_slot(clock_probe_size_class(nr))), pall == 1 ? 1 : 0,
+                       nimg > 1 ? 0 : lds_skew(strips, chunks), d_tbl);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -468,16 +482,18 @@ static int launch_fwd_f64lds(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, in
 // every EVEN filter length up to 40 runs the next instantiated length (zero-padded, see launch_fwd_f64lds)
 static int f64lds_padded_len(int hlen) { return (hlen >= 2 && hlen <= 40 && !(hlen & 1)) ? (hlen + 7) / 8 * 8 : 0; }
 
+// d_tbl != NULL: a batch of nimg images (five device pointers each) in one launch; small levels included (the size floor of the
+// single-image path -- below it the per-level launch is latency-bound either way -- does not apply: batching is what fills the chip)
 template <typename T>
-static int fwd2d_lds_any(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, int nc, int hlen, const Taps2<T>& f)
+static int fwd2d_lds_any(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, int nc, int hlen, const Taps2<T>& f, const void* d_tbl = nullptr, int nimg = 1)
 {
     const int hp = f64lds_padded_len(hlen);
     if (knob(KN_F64_LDS) < 1 || !hp || (hp != hlen && knob(KN_F64_LDS) == 3)) return 1;  // (3: exact lengths only)
     if (nr < 2 * kNIR || nr < hp || nc < hp) return 1;
-    if ((long long)nr * nc < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
+    if (!d_tbl && (long long)nr * nc < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
     switch (hp) {
 #define X(H) \
-    case H: return launch_fwd_f64lds<T, H>(in, cA, cH, cV, cD, nr, nc, hlen, f);
+    case H: return launch_fwd_f64lds<T, H>(in, cA, cH, cV, cD, nr, nc, hlen, f, d_tbl, nimg);
         PDWT_F64LDS_HLENS(X)
 #undef X
         default: return 1;
@@ -495,6 +511,12 @@ int fwd2d_f64_lds(const double* in, double* cA, double* cH, double* cV, double* 
 // there) and are tried first by the level driver; this is what runs otherwise -- longer banks (they ran the two-pass kernels, 2.67x
 // the traffic, and were SLOWER than their double-precision counterparts once those had moved here) and short banks on odd or
 // not-multiple-of-4 sizes (the LDS-tiled kernel before: 4095x4097 db4 L3 186 -> 116 us per pair, 1001x1003 69 -> 48)
+int fwd2d_f64_lds_batch(const void* d_tbl, int nimg, int nr, int nc, int hlen, const Taps2<double>& f)
+{
+    if (!d_tbl || nimg < 1 || nimg > 65535) return 1;
+    return fwd2d_lds_any<double>(nullptr, nullptr, nullptr, nullptr, nullptr, nr, nc, hlen, f, d_tbl, nimg);
+}
+
 int fwd2d_f32_lds(const float* in, float* cA, float* cH, float* cV, float* cD, int nr, int nc, int hlen, const Taps2<float>& f)
 {
     if (hlen <= 16 && knob(KN_F64_LDS) == 4) return 1;  // (4: long banks only, for comparison)
@@ -550,9 +572,18 @@ template <typename T, int HLEN, int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable<T> /*read through kernarg_taps()*/, const T* __restrict__ cA,
                                                           const T* __restrict__ cH, const T* __restrict__ cV,
                                                           const T* __restrict__ cD, T* __restrict__ out, int Nri, int Nci, int Nro, int Nco, int NP, int strips,
-                                                          unsigned long long* probe, int probe_all, int skew)
+                                                          unsigned long long* probe, int probe_all, int skew, const void* tbl)
 {
     clock_probe_stamp(probe, 0, probe_all);
+    if (tbl) {  // batched launch: (cA, cH, cV, cD, out) of this workgroup's image
+        typedef const unsigned long long __attribute__((address_space(4))) * tbl_t;
+        const tbl_t q = (tbl_t)(const unsigned long long*)tbl + 5 * (size_t)blockIdx.y;
+        cA = (const T*)q[0];
+        cH = (const T*)q[1];
+        cV = (const T*)q[2];
+        cD = (const T*)q[3];
+        out = (T*)q[4];
+    }
     using G = F64Inv<T, HLEN, NT>;
     using V2 = pair_t<T>;
     constexpr int ES = sizeof(T);
@@ -755,11 +786,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void k_inv2d_f64lds(TapTable
 // keep every product where it was)
 template <typename T, int HLEN>
 static int launch_inv_f64lds(const T* cA, const T* cH, const T* cV, const T* cD, T* out, int nri, int nci, int nro, int nco, int hlen,
-                             const Taps2<T>& f)
+                             const Taps2<T>& f, const void* d_tbl = nullptr, int nimg = 1)
 {
-    const bool big = (long long)nro * nco >= 2048LL * 2048;
+    const bool big = (long long)nro * nco * nimg >= 2048LL * 2048;
     const int strips = idiv_up(nci, F64Inv<T, HLEN, 256>::INCW);
-    const int target = big ? knob(KN_F64_LDS_WGS) : knob(KN_F64_LDS_WGS) / 2;
+    const int target = (big ? knob(KN_F64_LDS_WGS) : knob(KN_F64_LDS_WGS) / 2) / nimg;
     int chunks = std::max(1, target / strips);
     int NP = idiv_up(idiv_up(nri, chunks), 2) * 2;
     NP = std::max(NP, 2 * knob(KN_F64_LDS_MINGROUPS));
@@ -778,23 +809,25 @@ static int launch_inv_f64lds(const T* cA, const T* cH, const T* cV, const T* cD,
     if (strips * chunks > kClockProbeAllBlocks) pall = 0;
     KTimer kt(K_INV2D_F64);
     constexpr size_t lds256 = F64Inv<T, HLEN, 256>::kLdsBytes;
-    hipLaunchKernelGGL((k_inv2d_f64lds<T, HLEN, 256>), dim3(strips * chunks), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, nro, nco, NP, strips,
-                       pall == 2 ? pbuf : clock_probe_slot(8 + clock_probe_size_class(nro)), pall == 2 ? 1 : 0, lds_skew(strips, chunks));
+    if (nimg > 1) pall = 0;
+    hipLaunchKernelGGL((k_inv2d_f64lds<T, HLEN, 256>), dim3(strips * chunks, nimg), dim3(256), lds256, stream(), tt, cA, cH, cV, cD, out, nri, nci, nro, nco, NP, strips,
+                       pall == 2 ? pbuf : (nimg > 1 ? nullptr : clock_probe_slot(8 + clock_probe_size_class(nro))), pall == 2 ? 1 : 0,
+                       nimg > 1 ? 0 : lds_skew(strips, chunks), d_tbl);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
 
 template <typename T>
 static int inv2d_lds_any(const T* cA, const T* cH, const T* cV, const T* cD, T* out, int nri, int nci, int nro, int nco, int hlen,
-                         const Taps2<T>& f)
+                         const Taps2<T>& f, const void* d_tbl = nullptr, int nimg = 1)
 {
     const int hp = f64lds_padded_len(hlen);
     if (knob(KN_F64_LDS) < 1 || !hp || (hp != hlen && knob(KN_F64_LDS) == 3)) return 1;
     if (nri != div2(nro) || nci != div2(nco) || nri < hp || nci < 2) return 1;  // (row indices wrap at most once: wrap1)
-    if ((long long)nro * nco < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
+    if (!d_tbl && (long long)nro * nco < (long long)knob(KN_F64_LDS_MIN) * knob(KN_F64_LDS_MIN)) return 1;
     switch (hp) {
 #define X(H) \
-    case H: return launch_inv_f64lds<T, H>(cA, cH, cV, cD, out, nri, nci, nro, nco, hlen, f);
+    case H: return launch_inv_f64lds<T, H>(cA, cH, cV, cD, out, nri, nci, nro, nco, hlen, f, d_tbl, nimg);
         PDWT_F64LDS_HLENS(X)
 #undef X
         default: return 1;
@@ -806,6 +839,12 @@ int inv2d_f64_lds(const double* cA, const double* cH, const double* cV, const do
 {
     (void)taps_dev;
     return inv2d_lds_any<double>(cA, cH, cV, cD, out, nri, nci, nro, nco, hlen, f);
+}
+
+int inv2d_f64_lds_batch(const void* d_tbl, int nimg, int nri, int nci, int nro, int nco, int hlen, const Taps2<double>& f)
+{
+    if (!d_tbl || nimg < 1 || nimg > 65535) return 1;
+    return inv2d_lds_any<double>(nullptr, nullptr, nullptr, nullptr, nullptr, nri, nci, nro, nco, hlen, f, d_tbl, nimg);
 }
 
 int inv2d_f32_lds(const float* cA, const float* cH, const float* cV, const float* cD, float* out, int nri, int nci, int nro, int nco,

@@ -1026,6 +1026,35 @@ def test_swt_fused_levels_18_and_20_taps():
             assert band_err(W2.get_image(), W.get_image()) <= 1e-5
 
 
+@pytest.mark.parametrize("wname", ["db11", "db12", "db13", "db16", "sym17", "db20", "bior6.8"])
+def test_swt_fused_levels_22_to_40_taps(wname):
+    """Round 5: banks of 22 ... 40 taps run the two-columns-per-thread fused level kernels (swt_fused_l2.inc) at the
+    next of 24 / 32 / 40 taps, zero-padded symmetrically.  Forward bands bit-identical to the two-pass kernels (knob swtf_long = 0) and
+    equal to the oracle; inverse within the SWT tolerance of both.  Spacings 1, 2, 4 (three levels), a width that is not a tile multiple."""
+    rs = np.random.RandomState(43)
+    for shape, levels in (((512, 1024), 3), ((384, 1320), 2)):
+        x = rs.uniform(0, 255, shape).astype(np.float32)
+        W = pdwt_amd.Wavelets(x, wname, levels, do_swt=1)
+        assert W.info.nlevels == levels
+        O = orc.OracleWavelets(x, wname, levels, do_swt=1)
+        W.forward()
+        O.forward()
+        for g, o in zip(W.coeffs, O.coeffs):
+            assert band_err(g, o) <= 1e-5, (wname, shape)
+        c = W.coeffs
+        W.inverse()
+        O.inverse()
+        assert band_err(W.get_image(), O.get_image()) <= 1e-5, (wname, shape)
+        assert band_err(W.get_image(), x) <= 1e-5, (wname, shape)
+        with knobs(swtf_long=0):
+            W2 = pdwt_amd.Wavelets(x, wname, levels, do_swt=1)
+            W2.forward()
+            for g, o in zip(c, W2.coeffs):
+                assert np.array_equal(g, o), (wname, shape)  # forward: the same sums in the same order, the padding adds exact zeros
+            W2.inverse()
+            assert band_err(W2.get_image(), W.get_image()) <= 1e-5
+
+
 def test_swt_fused_levels_double_precision():
     """swt_fused_f64.inc: one launch per SWT level in double precision.  Forward bands bit-identical to the two-pass kernels and
     equal to the oracle; inverse (rows before columns, like the float32 fused inverse) within 1e-12 of both."""
@@ -1207,18 +1236,29 @@ def test_padded_banks_with_non_finite_samples():
 
 @pytest.mark.parametrize("case", [(12, 512, 512, "db4", 3, np.float32), (5, 256, 384, "sym8", 2, np.float32), (3, 1024, 512, "db2", 4, np.float32),
                                   (4, 250, 250, "db4", 2, np.float32), (3, 256, 256, "db4", 2, np.float64),
+                                  # round 5: the double build batches too (fused double-precision level kernels, gridDim.y = image): long banks,
+                                  # small levels (64 -> 32 rows), odd sizes, a bank that is zero-padded to the next multiple of 8
+                                  (6, 512, 512, "db20", 3, np.float64), (4, 384, 640, "sym8", 3, np.float64), (3, 255, 321, "db4", 2, np.float64),
+                                  (5, 256, 256, "db5", 4, np.float64), (3, 64, 64, "db2", 1, np.float64), (3, 2048, 2048, "db20", 2, np.float64),
                                   # the cascade kernels with a batch dimension (gridDim.y = image): the C2 geometry (straight-line wave
                                   # programs), a two-level transform, and four levels (the coarsest one on the per-level kernels)
                                   (3, 4096, 4096, "db4", 3, np.float32), (3, 2048, 2048, "db4", 2, np.float32), (3, 2048, 4096, "db2", 4, np.float32)])
 def test_image_batch_one_launch_per_level(case):
     """include/wt_batch.h WaveletsImages / pdwt_batch2d_*: a batch of equally sized images, every level of ALL images in one launch
     of the streaming level kernels (gridDim.y = image).  Bands and reconstructions equal the per-image transforms bit for bit
-    (and the oracle within tolerance); geometries outside the streaming kernels (250 x 250) and the double build fall back to
-    image-after-image and give the same results."""
+    (and the oracle within tolerance); geometries outside the streaming kernels (250 x 250 in float32) fall back to image-after-image
+    and give the same results.  The double build batches through the fused level kernels of dwt_lds.hip (round 5)."""
     B, nr, nc, wname, lev, dt = case
     x = np.random.RandomState(21).uniform(0, 255, (B, nr, nc)).astype(dt)
     IB = pdwt_amd.ImageBatch(x, wname, lev)
-    expect_batched = dt == np.float32 and nr % (4 << (lev - 1)) == 0 and nc % (4 << (lev - 1)) == 0
+    if dt == np.float32:
+        expect_batched = nr % (4 << (lev - 1)) == 0 and nc % (4 << (lev - 1)) == 0
+    else:  # every level at least 16 rows and the padded bank length in either direction
+        hp = (IB[0].info.hlen + 7) // 8 * 8
+        rr, cc, expect_batched = nr, nc, True
+        for _ in range(IB[0].info.nlevels):
+            expect_batched = expect_batched and rr >= max(16, hp) and cc >= hp
+            rr, cc = (rr + 1) // 2, (cc + 1) // 2
     assert IB.batched == expect_batched, (IB.batched, expect_batched)
     IB.forward()
     singles = []
