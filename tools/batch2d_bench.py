@@ -15,8 +15,9 @@ ap.add_argument("--B", type=int, default=64)
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--wname", default="db4")
 ap.add_argument("--levels", type=int, default=3)
+ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
 a = ap.parse_args()
-x = torch.rand(a.B, a.size, a.size, device="cuda") * 255
+x = torch.rand(a.B, a.size, a.size, device="cuda", dtype=torch.float64 if a.dtype == "float64" else torch.float32) * 255
 L = pdwt_amd.hip()
 
 
@@ -47,7 +48,7 @@ def batch():
 
 
 t_s, t_b = timed(singles), timed(batch)
-nbytes = a.B * a.size * a.size * 4
+nbytes = a.B * a.size * a.size * (8 if a.dtype == "float64" else 4)
 y = torch.empty_like(x)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
