@@ -112,6 +112,9 @@ int pdwt_graph_destroy(void* exec);
  * pdwt_forward_separable_f32 (pdwt_create_coeffs_buffer_f32, pdwt_tmp_elems); every level of ALL images runs in ONE launch.
  * create returns NULL when the geometry is outside the streaming level kernels (then run the images one by one); the object
  * only keeps device-side pointer tables: images, bands and scratch stay the caller's and must outlive it.
+ * Round 5: `info` may also describe a Haar transform (hlen 2: one launch per level of the Haar kernels, any size, either precision) or,
+ * in float32, an undecimated one (do_swt = 1: one launch per level of the fused SWT level kernels, banks of up to 40 taps; bands and
+ * scratch as for pdwt_forward_swt_separable_f32) -- the same create / forward / inverse / destroy entry points.
  * ------------------------------------------------------------------------------------------- */
 void* pdwt_batch2d_create_f32(int nimg, float* const* d_images, float** const* d_coeffs, float* const* d_tmps, pdwt_info info);
 int pdwt_batch2d_forward_f32(void* batch, const pdwt_filters_f32* f);

@@ -162,11 +162,12 @@ class WaveletsImages {
     std::vector<Wavelets*> img;
     int Nr, Nc;
 
-    /* imgs: B contiguous Nr x Nc images (host, or device when memisonhost = 0) */
-    WaveletsImages(DTYPE* imgs, int B, int Nr_, int Nc_, const char* wname, int levels, int memisonhost = 1) : Nr(Nr_), Nc(Nc_), batch_(NULL)
+    /* imgs: B contiguous Nr x Nc images (host, or device when memisonhost = 0); do_swt = 1: the undecimated transform (one launch per level
+     * over all images in the float build when every level is inside the fused SWT level kernels; image after image otherwise) */
+    WaveletsImages(DTYPE* imgs, int B, int Nr_, int Nc_, const char* wname, int levels, int memisonhost = 1, int do_swt = 0) : Nr(Nr_), Nc(Nc_), batch_(NULL)
     {
         for (int b = 0; b < B; b++) {
-            img.push_back(new Wavelets(imgs + (size_t)b * Nr * Nc, Nr, Nc, wname, levels, memisonhost, 1, 0, 0, 2));
+            img.push_back(new Wavelets(imgs + (size_t)b * Nr * Nc, Nr, Nc, wname, levels, memisonhost, 1, 0, do_swt, 2));
             /* the batched launches write the bands behind the instances' backs: no norm kept from a threshold pass, whatever
              * set_norm_cache() / PDWT_NORM_IN_THRESHOLD say later (taking a raw band pointer switches that shortcut off for good) */
             img.back()->set_norm_cache(0);
@@ -182,7 +183,12 @@ class WaveletsImages {
             }
             const w_info w = img[0]->winfos;
             pdwt_info info = {w.ndims, w.Nr, w.Nc, w.nlevels, w.do_swt, w.hlen};
-            if (WB_COMPUTE_FILTERS(wname, 0, &bank_) == w.hlen) batch_ = WB_CREATE(B, di.data(), dc.data(), dt.data(), info);
+#ifdef DOUBLEPRECISION
+            const bool kind_ok = !w.do_swt; /* (the double build batches the decimated transform and Haar) */
+#else
+            const bool kind_ok = true;
+#endif
+            if (kind_ok && WB_COMPUTE_FILTERS(wname, w.do_swt, &bank_) == w.hlen) batch_ = WB_CREATE(B, di.data(), dc.data(), dt.data(), info);
         }
     }
     ~WaveletsImages()

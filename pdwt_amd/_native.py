@@ -195,6 +195,8 @@ def host(dtype):
             getattr(L, "pdwt_wavelets_" + n).argtypes = [vp]
         L.pdwt_images_new.restype = vp
         L.pdwt_images_new.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci]
+        L.pdwt_images_new_swt.restype = vp
+        L.pdwt_images_new_swt.argtypes = [vp, ci, ci, ci, C.c_char_p, ci, ci, ci]
         L.pdwt_images_at.restype = vp
         L.pdwt_images_at.argtypes = [vp, ci]
         for n in ("delete", "ok", "batched", "forward", "inverse"):

@@ -850,7 +850,46 @@ static int inverse_separable_1d(T* d_image, T** c, T* d_tmp, pdwt_info w, const 
 // built once: 2 L launches per batch and direction instead of 2 L B.  Same kernels, same arithmetic: results are those of the
 // per-image transforms bit for bit.  The reference has no batched entry (its TODO.txt:15 lists multi-GPU / batching as future work).
 static inline bool b2_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+// (every batch object starts with its kind: 0 = float32 streaming / cascade levels, 1 = double-precision fused levels, 2 = Haar)
+template <typename T> void* haar_batch_create(int nimg, T* const* d_images, T** const* d_coeffs, T* const* d_tmps, pdwt_info w);  // haar.hip
+template <typename T> int haar_batch_forward(void* batch);
+template <typename T> int haar_batch_inverse(void* batch);
+template <typename T> void haar_batch_destroy(void* batch);
+void* swt_batch_create_f32(int nimg, float* const* d_images, float** const* d_coeffs, float* const* d_tmps, pdwt_info w);  // swt.hip
+int swt_batch_forward_f32(void* batch, const pdwt_filters_f32* filt);
+int swt_batch_inverse_f32(void* batch, const pdwt_filters_f32* filt);
+void swt_batch_destroy_f32(void* batch);
+struct BatchHaar {  // (kind 2: Haar; kind 3: float32 SWT -- hb is the object of haar.hip / swt.hip)
+    int kind, dev;
+    void* hb;
+};
+static void* batch_swt_create(int nimg, float* const* d_images, float** const* d_coeffs, float* const* d_tmps, pdwt_info w)
+{
+    BatchHaar* B = new (std::nothrow) BatchHaar();
+    if (!B) return nullptr;
+    B->kind = 3;
+    B->hb = (hipGetDevice(&B->dev) == hipSuccess) ? swt_batch_create_f32(nimg, d_images, d_coeffs, d_tmps, w) : nullptr;
+    if (!B->hb) {
+        delete B;
+        return nullptr;
+    }
+    return B;
+}
+template <typename T>
+static void* batch_haar_create(int nimg, T* const* d_images, T** const* d_coeffs, T* const* d_tmps, pdwt_info w)
+{
+    BatchHaar* B = new (std::nothrow) BatchHaar();
+    if (!B) return nullptr;
+    B->kind = 2;
+    B->hb = (hipGetDevice(&B->dev) == hipSuccess) ? haar_batch_create<T>(nimg, d_images, d_coeffs, d_tmps, w) : nullptr;
+    if (!B->hb) {
+        delete B;
+        return nullptr;
+    }
+    return B;
+}
 struct Batch2D {
+    int kind;
     int nimg, dev;
     pdwt_info w;
     size_t trash_floats;
@@ -883,6 +922,7 @@ static Batch2D* batch2d_create(int nimg, float* const* d_images, float** const* 
     if (probe.trash_floats < 1024) return nullptr;
     Batch2D* B = new (std::nothrow) Batch2D();
     if (!B) return nullptr;
+    B->kind = 0;
     B->nimg = nimg;
     B->w = w;
     B->trash_floats = probe.trash_floats;
@@ -1046,6 +1086,7 @@ static int batch2d_inverse(Batch2D* B, const pdwt_filters_f32* filt)
 // run batched as well.  Same kernels, same arithmetic: bit-identical to the per-image transforms.
 // -------------------------------------------------------------------------------------------------
 struct Batch2D64 {
+    int kind;
     int nimg, dev;
     pdwt_info w;
     int lev_nr[34], lev_nc[34];
@@ -1059,6 +1100,7 @@ static Batch2D64* batch2d_create_f64(int nimg, double* const* d_images, double**
     if (force_twopass() || w.hlen < 2 || w.hlen > 40 || (w.hlen & 1) || knob(KN_F64_LDS) < 1) return nullptr;
     Batch2D64* B = new (std::nothrow) Batch2D64();
     if (!B) return nullptr;
+    B->kind = 1;
     B->nimg = nimg;
     B->w = w;
     B->d_fwd = B->d_inv = nullptr;
@@ -1157,14 +1199,36 @@ static int batch2d_inverse_f64(Batch2D64* B, const pdwt_filters_f64* filt)
 using namespace pdwt;
 
 extern "C" {
+// (a Haar bank -- hlen 2, the transform the class sends to pdwt_haar_* -- batches through the Haar kernels, either precision)
+static bool batch_is_haar(const pdwt_info& w) { return w.hlen == 2 && w.ndims == 2 && !w.do_swt; }
 void* pdwt_batch2d_create_f64(int nimg, double* const* d_images, double** const* d_coeffs, double* const* d_tmps, pdwt_info info)
 {
+    if (batch_is_haar(info)) return batch_haar_create<double>(nimg, d_images, d_coeffs, d_tmps, info);
     return batch2d_create_f64(nimg, d_images, d_coeffs, d_tmps, info);
 }
-int pdwt_batch2d_forward_f64(void* batch, const pdwt_filters_f64* f) { return batch2d_forward_f64((Batch2D64*)batch, f); }
-int pdwt_batch2d_inverse_f64(void* batch, const pdwt_filters_f64* f) { return batch2d_inverse_f64((Batch2D64*)batch, f); }
+int pdwt_batch2d_forward_f64(void* batch, const pdwt_filters_f64* f)
+{
+    if (batch && *(const int*)batch == 2) {
+        Batch2DDev on_dev(((BatchHaar*)batch)->dev);
+        return haar_batch_forward<double>(((BatchHaar*)batch)->hb);
+    }
+    return batch2d_forward_f64((Batch2D64*)batch, f);
+}
+int pdwt_batch2d_inverse_f64(void* batch, const pdwt_filters_f64* f)
+{
+    if (batch && *(const int*)batch == 2) {
+        Batch2DDev on_dev(((BatchHaar*)batch)->dev);
+        return haar_batch_inverse<double>(((BatchHaar*)batch)->hb);
+    }
+    return batch2d_inverse_f64((Batch2D64*)batch, f);
+}
 void pdwt_batch2d_destroy_f64(void* batch)
 {
+    if (batch && *(const int*)batch == 2) {
+        haar_batch_destroy<double>(((BatchHaar*)batch)->hb);
+        delete (BatchHaar*)batch;
+        return;
+    }
     Batch2D64* B = (Batch2D64*)batch;
     if (!B) return;
     pdwt_free(B->d_fwd);
@@ -1173,12 +1237,46 @@ void pdwt_batch2d_destroy_f64(void* batch)
 }
 void* pdwt_batch2d_create_f32(int nimg, float* const* d_images, float** const* d_coeffs, float* const* d_tmps, pdwt_info info)
 {
+    if (batch_is_haar(info)) return batch_haar_create<float>(nimg, d_images, d_coeffs, d_tmps, info);
+    if (info.do_swt) return batch_swt_create(nimg, d_images, d_coeffs, d_tmps, info);
     return batch2d_create(nimg, d_images, d_coeffs, d_tmps, info, info.hlen);
 }
-int pdwt_batch2d_forward_f32(void* batch, const pdwt_filters_f32* f) { return batch2d_forward((Batch2D*)batch, f); }
-int pdwt_batch2d_inverse_f32(void* batch, const pdwt_filters_f32* f) { return batch2d_inverse((Batch2D*)batch, f); }
+int pdwt_batch2d_forward_f32(void* batch, const pdwt_filters_f32* f)
+{
+    if (batch && *(const int*)batch == 2) {
+        Batch2DDev on_dev(((BatchHaar*)batch)->dev);
+        return haar_batch_forward<float>(((BatchHaar*)batch)->hb);
+    }
+    if (batch && *(const int*)batch == 3) {
+        Batch2DDev on_dev(((BatchHaar*)batch)->dev);
+        return swt_batch_forward_f32(((BatchHaar*)batch)->hb, f);
+    }
+    return batch2d_forward((Batch2D*)batch, f);
+}
+int pdwt_batch2d_inverse_f32(void* batch, const pdwt_filters_f32* f)
+{
+    if (batch && *(const int*)batch == 2) {
+        Batch2DDev on_dev(((BatchHaar*)batch)->dev);
+        return haar_batch_inverse<float>(((BatchHaar*)batch)->hb);
+    }
+    if (batch && *(const int*)batch == 3) {
+        Batch2DDev on_dev(((BatchHaar*)batch)->dev);
+        return swt_batch_inverse_f32(((BatchHaar*)batch)->hb, f);
+    }
+    return batch2d_inverse((Batch2D*)batch, f);
+}
 void pdwt_batch2d_destroy(void* batch)
 {
+    if (batch && *(const int*)batch == 2) {
+        haar_batch_destroy<float>(((BatchHaar*)batch)->hb);
+        delete (BatchHaar*)batch;
+        return;
+    }
+    if (batch && *(const int*)batch == 3) {
+        swt_batch_destroy_f32(((BatchHaar*)batch)->hb);
+        delete (BatchHaar*)batch;
+        return;
+    }
     Batch2D* B = (Batch2D*)batch;
     if (!B) return;
     pdwt_free(B->d_fwd);

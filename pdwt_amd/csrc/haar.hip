@@ -9,6 +9,9 @@
 // thread per output sample and loads each coefficient four times, src/haar.cu:45-48); lanes run
 // along x; in the aligned even-size case each thread moves 2 quads with 16-byte loads / 8-byte
 // stores (forward) or 8-byte loads / 16-byte stores (inverse).
+#include <new>
+#include <vector>
+
 #include "common.hpp"
 
 namespace pdwt {
@@ -36,8 +39,17 @@ __device__ __forceinline__ void butterfly(T a, T b, T c, T d, T& A, T& H, T& V, 
 // forward 2D: in Nr x Nc -> 4 bands Nr2 x Nc2.  VEC: Nc % 4 == 0 and Nr even -> 2 quads / thread.
 template <typename T, bool VEC>
 __global__ __launch_bounds__(kHaarThreads) void k_haar2d_fwd(const T* __restrict__ in, T* __restrict__ cA, T* __restrict__ cH,
-                                                             T* __restrict__ cV, T* __restrict__ cD, int Nr, int Nc)
+                                                             T* __restrict__ cV, T* __restrict__ cD, int Nr, int Nc, const void* tbl)
 {
+    if (tbl) {  // batched launch (pdwt_batch2d_*): gridDim.z = image, five pointers per image (in, cA, cH, cV, cD)
+        typedef const unsigned long long __attribute__((address_space(4))) * tbl_t;
+        const tbl_t q = (tbl_t)(const unsigned long long*)tbl + 5 * (size_t)blockIdx.z;
+        in = (const T*)q[0];
+        cA = (T*)q[1];
+        cH = (T*)q[2];
+        cV = (T*)q[3];
+        cD = (T*)q[4];
+    }
     const int Nr2 = div2(Nr), Nc2 = div2(Nc);
     const int gy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (gy >= Nr2) return;
@@ -79,8 +91,17 @@ __global__ __launch_bounds__(kHaarThreads) void k_haar2d_fwd(const T* __restrict
 template <typename T, bool VEC>
 __global__ __launch_bounds__(kHaarThreads) void k_haar2d_inv(T* __restrict__ out, const T* __restrict__ cA, const T* __restrict__ cH,
                                                              const T* __restrict__ cV, const T* __restrict__ cD, int Nri, int Nci, int Nro,
-                                                             int Nco)
+                                                             int Nco, const void* tbl)
 {
+    if (tbl) {  // batched launch: (out, cA, cH, cV, cD) of image blockIdx.z
+        typedef const unsigned long long __attribute__((address_space(4))) * tbl_t;
+        const tbl_t q = (tbl_t)(const unsigned long long*)tbl + 5 * (size_t)blockIdx.z;
+        out = (T*)q[0];
+        cA = (const T*)q[1];
+        cH = (const T*)q[2];
+        cV = (const T*)q[3];
+        cD = (const T*)q[4];
+    }
     const int gy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (gy >= Nri) return;
     if constexpr (VEC) {  // Nci even, Nco == 2*Nci, Nro == 2*Nri
@@ -153,35 +174,39 @@ template <typename T>
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <typename T>
-static int haar2d_fwd_level(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, int nc)
+static int haar2d_fwd_level(const T* in, T* cA, T* cH, T* cV, T* cD, int nr, int nc, const void* d_tbl = nullptr, int nimg = 1, bool tbl_vec = false)
 {
     const int nr2 = div2(nr), nc2 = div2(nc);
-    const bool vec = (nc % 4 == 0) && (nr % 2 == 0) && aligned16<T>(in) && aligned16<T>(cA) && aligned16<T>(cH) && aligned16<T>(cV) &&
-                     aligned16<T>(cD) && sizeof(T) == 4;
+    // (a batch: the caller has checked the alignment of every image's pointers)
+    const bool vec = d_tbl ? tbl_vec
+                           : (nc % 4 == 0) && (nr % 2 == 0) && aligned16<T>(in) && aligned16<T>(cA) && aligned16<T>(cH) && aligned16<T>(cV) &&
+                                 aligned16<T>(cD) && sizeof(T) == 4;
     KTimer kt(K_HAAR2D_FWD);
     if (vec) {
-        dim3 grid(idiv_up(nc2 / 2, 64), idiv_up(nr2, 4));
-        hipLaunchKernelGGL((k_haar2d_fwd<T, true>), grid, dim3(kHaarThreads), 0, stream(), in, cA, cH, cV, cD, nr, nc);
+        dim3 grid(idiv_up(nc2 / 2, 64), idiv_up(nr2, 4), nimg);
+        hipLaunchKernelGGL((k_haar2d_fwd<T, true>), grid, dim3(kHaarThreads), 0, stream(), in, cA, cH, cV, cD, nr, nc, d_tbl);
     } else {
-        dim3 grid(idiv_up(nc2, 64), idiv_up(nr2, 4));
-        hipLaunchKernelGGL((k_haar2d_fwd<T, false>), grid, dim3(kHaarThreads), 0, stream(), in, cA, cH, cV, cD, nr, nc);
+        dim3 grid(idiv_up(nc2, 64), idiv_up(nr2, 4), nimg);
+        hipLaunchKernelGGL((k_haar2d_fwd<T, false>), grid, dim3(kHaarThreads), 0, stream(), in, cA, cH, cV, cD, nr, nc, d_tbl);
     }
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
 
 template <typename T>
-static int haar2d_inv_level(T* out, const T* cA, const T* cH, const T* cV, const T* cD, int nri, int nci, int nro, int nco)
+static int haar2d_inv_level(T* out, const T* cA, const T* cH, const T* cV, const T* cD, int nri, int nci, int nro, int nco, const void* d_tbl = nullptr,
+                            int nimg = 1, bool tbl_vec = false)
 {
-    const bool vec = (nci % 2 == 0) && (nco == 2 * nci) && (nro == 2 * nri) && aligned16<T>(out) && aligned16<T>(cA) && aligned16<T>(cH) &&
-                     aligned16<T>(cV) && aligned16<T>(cD) && sizeof(T) == 4;
+    const bool vec = d_tbl ? tbl_vec
+                           : (nci % 2 == 0) && (nco == 2 * nci) && (nro == 2 * nri) && aligned16<T>(out) && aligned16<T>(cA) && aligned16<T>(cH) &&
+                                 aligned16<T>(cV) && aligned16<T>(cD) && sizeof(T) == 4;
     KTimer kt(K_HAAR2D_INV);
     if (vec) {
-        dim3 grid(idiv_up(nci / 2, 64), idiv_up(nri, 4));
-        hipLaunchKernelGGL((k_haar2d_inv<T, true>), grid, dim3(kHaarThreads), 0, stream(), out, cA, cH, cV, cD, nri, nci, nro, nco);
+        dim3 grid(idiv_up(nci / 2, 64), idiv_up(nri, 4), nimg);
+        hipLaunchKernelGGL((k_haar2d_inv<T, true>), grid, dim3(kHaarThreads), 0, stream(), out, cA, cH, cV, cD, nri, nci, nro, nco, d_tbl);
     } else {
-        dim3 grid(idiv_up(nci, 64), idiv_up(nri, 4));
-        hipLaunchKernelGGL((k_haar2d_inv<T, false>), grid, dim3(kHaarThreads), 0, stream(), out, cA, cH, cV, cD, nri, nci, nro, nco);
+        dim3 grid(idiv_up(nci, 64), idiv_up(nri, 4), nimg);
+        hipLaunchKernelGGL((k_haar2d_inv<T, false>), grid, dim3(kHaarThreads), 0, stream(), out, cA, cH, cV, cD, nri, nci, nro, nco, d_tbl);
     }
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
@@ -232,6 +257,123 @@ static int haar_inverse2d(T* d_image, T** c, T* d_tmp, pdwt_info w)
     }
     return PDWT_OK;
 }
+
+// -------------------------------------------------------------------------------------------------
+// a batch of equally sized images (pdwt_batch2d_*, dwt.hip, when the bank is Haar): every level of all images in one launch
+// (gridDim.z = image), the per-image pointers of haar_forward2d / haar_inverse2d in device-side tables built once
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+struct HaarBatch {
+    int nimg, L;
+    int nr[34], nc[34];
+    bool fvec[33], ivec[33];       // 16-byte form of the level (every image's pointers aligned)
+    unsigned long long* d_fwd;     // [level][image][5]: in, cA, cH, cV, cD
+    unsigned long long* d_inv;     // [level][image][5]: out, cA, cH, cV, cD
+};
+template <typename T>
+void* haar_batch_create(int nimg, T* const* d_images, T** const* d_coeffs, T* const* d_tmps, pdwt_info w)
+{
+    if (nimg < 1 || nimg > 65535 || !d_images || !d_coeffs || !d_tmps || w.ndims != 2 || w.do_swt || w.nlevels < 1 || w.nlevels > 32) return nullptr;
+    HaarBatch<T>* B = new (std::nothrow) HaarBatch<T>();
+    if (!B) return nullptr;
+    B->nimg = nimg;
+    B->L = w.nlevels;
+    B->d_fwd = B->d_inv = nullptr;
+    B->nr[0] = w.Nr;
+    B->nc[0] = w.Nc;
+    for (int i = 1; i <= B->L; i++) {
+        B->nr[i] = div2(B->nr[i - 1]);
+        B->nc[i] = div2(B->nc[i - 1]);
+    }
+    const int L = B->L;
+    std::vector<unsigned long long> hf((size_t)L * nimg * 5), hi((size_t)L * nimg * 5);
+    for (int lev = 0; lev < L; lev++) {
+        B->fvec[lev] = sizeof(T) == 4 && (B->nc[lev] % 4 == 0) && (B->nr[lev] % 2 == 0);
+        B->ivec[lev] = sizeof(T) == 4 && (B->nc[lev + 1] % 2 == 0) && (B->nc[lev] == 2 * B->nc[lev + 1]) && (B->nr[lev] == 2 * B->nr[lev + 1]);
+    }
+    for (int b = 0; b < nimg; b++) {
+        T* const* c = d_coeffs[b];
+        if (!d_images[b] || !c || !d_tmps[b]) {
+            delete B;
+            return nullptr;
+        }
+        T* ping[2] = {d_tmps[b], d_tmps[b] + up64((size_t)div2(w.Nr) * div2(w.Nc))};
+        const T* in = d_images[b];
+        for (int lev = 0; lev < L; lev++) {  // haar_forward2d
+            T* aout = (lev == L - 1) ? c[0] : ping[lev & 1];
+            const void* e5[5] = {in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3]};
+            for (int k = 0; k < 5; k++) {
+                if (!e5[k]) {
+                    delete B;
+                    return nullptr;
+                }
+                hf[((size_t)lev * nimg + b) * 5 + k] = (unsigned long long)(uintptr_t)e5[k];
+                B->fvec[lev] = B->fvec[lev] && aligned16<T>(e5[k]);
+            }
+            in = aout;
+        }
+        const T* a = c[0];
+        for (int i = L - 1; i >= 0; i--) {  // haar_inverse2d
+            T* out = (i == 0) ? d_images[b] : ping[i & 1];
+            const void* e5[5] = {out, a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3]};
+            for (int k = 0; k < 5; k++) {
+                hi[((size_t)i * nimg + b) * 5 + k] = (unsigned long long)(uintptr_t)e5[k];
+                B->ivec[i] = B->ivec[i] && aligned16<T>(e5[k]);
+            }
+            a = out;
+        }
+    }
+    const size_t bytes = hf.size() * sizeof(unsigned long long);
+    B->d_fwd = (unsigned long long*)pdwt_malloc(bytes);
+    B->d_inv = (unsigned long long*)pdwt_malloc(bytes);
+    if (!B->d_fwd || !B->d_inv || pdwt_memcpy_h2d(B->d_fwd, hf.data(), bytes) != PDWT_OK || pdwt_memcpy_h2d(B->d_inv, hi.data(), bytes) != PDWT_OK) {
+        pdwt_free(B->d_fwd);
+        pdwt_free(B->d_inv);
+        delete B;
+        return nullptr;
+    }
+    return B;
+}
+template <typename T>
+int haar_batch_forward(void* batch)
+{
+    HaarBatch<T>* B = (HaarBatch<T>*)batch;
+    if (!B) return PDWT_EINVAL;
+    for (int lev = 0; lev < B->L; lev++) {
+        const int rc = haar2d_fwd_level<T>(nullptr, nullptr, nullptr, nullptr, nullptr, B->nr[lev], B->nc[lev], B->d_fwd + (size_t)lev * B->nimg * 5, B->nimg, B->fvec[lev]);
+        if (rc != PDWT_OK) return rc;
+    }
+    return PDWT_OK;
+}
+template <typename T>
+int haar_batch_inverse(void* batch)
+{
+    HaarBatch<T>* B = (HaarBatch<T>*)batch;
+    if (!B) return PDWT_EINVAL;
+    for (int i = B->L - 1; i >= 0; i--) {
+        const int rc = haar2d_inv_level<T>(nullptr, nullptr, nullptr, nullptr, nullptr, B->nr[i + 1], B->nc[i + 1], B->nr[i], B->nc[i], B->d_inv + (size_t)i * B->nimg * 5, B->nimg,
+                                           B->ivec[i]);
+        if (rc != PDWT_OK) return rc;
+    }
+    return PDWT_OK;
+}
+template <typename T>
+void haar_batch_destroy(void* batch)
+{
+    HaarBatch<T>* B = (HaarBatch<T>*)batch;
+    if (!B) return;
+    pdwt_free(B->d_fwd);
+    pdwt_free(B->d_inv);
+    delete B;
+}
+template void* haar_batch_create<float>(int, float* const*, float** const*, float* const*, pdwt_info);
+template void* haar_batch_create<double>(int, double* const*, double** const*, double* const*, pdwt_info);
+template int haar_batch_forward<float>(void*);
+template int haar_batch_forward<double>(void*);
+template int haar_batch_inverse<float>(void*);
+template int haar_batch_inverse<double>(void*);
+template void haar_batch_destroy<float>(void*);
+template void haar_batch_destroy<double>(void*);
 
 // haar_forward1d, src/haar.cu:163-186
 template <typename T>

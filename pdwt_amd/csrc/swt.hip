@@ -9,6 +9,9 @@
 #include <type_traits>
 
 #include "cols_ring.hpp"
+#include <new>
+#include <vector>
+
 #include "common.hpp"
 #include "swt_fused.hpp"
 
@@ -433,6 +436,127 @@ static int inverse_swt_1d(T* d_image, T** c, T* d_tmp, pdwt_info w, const typena
         a = out;
     }
     return PDWT_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// a batch of equally sized float32 images through the fused SWT level kernels (pdwt_batch2d_* on instances created with do_swt = 1,
+// dwt.hip): every level of ALL images in one launch (gridDim.z = image), the per-image pointers of forward_swt / inverse_swt -- the
+// approximation ping-pongs through the two halves of each image's d_tmp -- in device-side tables built once.  NULL when a level of the
+// geometry is outside the fused kernels (the caller then transforms image after image).
+// -------------------------------------------------------------------------------------------------
+struct SwtBatch {
+    int nimg, L, Nr, Nc, hlen;
+    unsigned long long* d_fwd;  // [level][image][5]: in, cA, cH, cV, cD
+    unsigned long long* d_inv;  // [level][image][5]: cA, cH, cV, cD, out
+};
+static bool swt_batch_level_ok(int Nr, int Nc, int hlen, int fct)
+{
+    // the geometry rules of swt_fwd_fused_f32 / swt_inv_fused_f32 and of their launchers (swt_fused.inc, swt_fused_l2.inc)
+    if ((hlen & 1) || hlen < 2 || hlen > 40) return false;
+    const bool l2 = hlen > 20;
+    const int H = l2 ? (hlen <= 24 ? 24 : (hlen <= 32 ? 32 : 40)) : hlen, tile = l2 ? 512 : 1024;
+    if ((Nc & 3) || Nc < 64 || (Nr % fct) != 0 || Nr / fct < 2 * H) return false;
+    for (int inv = 0; inv < 2; inv++) {
+        const int C = inv ? H / 2 : H / 2 - 1;
+        const int HLc = ((C * fct + 3) >> 2) << 2, HRc = (((H - 1 - C) * fct + 3) >> 2) << 2;
+        const int PW = HLc + tile + HRc;
+        if (PW / 4 > 512 || PW - tile > Nc) return false;
+        if (inv && 2 * 4 * (size_t)PW * sizeof(float) + 64 > 64 * 1024) return false;
+    }
+    return true;
+}
+void* swt_batch_create_f32(int nimg, float* const* d_images, float** const* d_coeffs, float* const* d_tmps, pdwt_info w)
+{
+    if (nimg < 1 || nimg > 65535 || !d_images || !d_coeffs || !d_tmps || w.ndims != 2 || !w.do_swt || w.nlevels < 1 || w.nlevels > 30) return nullptr;
+    if (knob(KN_SWTF) != 1 || (w.hlen > 20 && knob(KN_SWTF_LONG) != 1)) return nullptr;
+    for (int lev = 0; lev < w.nlevels; lev++)
+        if (!swt_batch_level_ok(w.Nr, w.Nc, w.hlen, 1 << lev)) return nullptr;
+    SwtBatch* B = new (std::nothrow) SwtBatch();
+    if (!B) return nullptr;
+    B->nimg = nimg;
+    B->L = w.nlevels;
+    B->Nr = w.Nr;
+    B->Nc = w.Nc;
+    B->hlen = w.hlen;
+    B->d_fwd = B->d_inv = nullptr;
+    const int L = B->L;
+    std::vector<unsigned long long> hf((size_t)L * nimg * 5), hi((size_t)L * nimg * 5);
+    auto al = [](const void* p) { return p && ((uintptr_t)p & 15) == 0; };
+    for (int b = 0; b < nimg; b++) {
+        float* const* c = d_coeffs[b];
+        if (!d_images[b] || !c || !d_tmps[b]) {
+            delete B;
+            return nullptr;
+        }
+        float* t1 = d_tmps[b];
+        float* t2 = d_tmps[b] + (size_t)w.Nr * w.Nc;
+        const float* in = d_images[b];
+        for (int lev = 0; lev < L; lev++) {  // forward_swt's level loop
+            float* aout = (lev == L - 1) ? c[0] : ((lev & 1) ? t2 : t1);
+            const void* e5[5] = {in, aout, c[3 * lev + 1], c[3 * lev + 2], c[3 * lev + 3]};
+            for (int k = 0; k < 5; k++) {
+                if (!al(e5[k]) || (k > 0 && e5[k] == e5[0])) {
+                    delete B;
+                    return nullptr;
+                }
+                hf[((size_t)lev * nimg + b) * 5 + k] = (unsigned long long)(uintptr_t)e5[k];
+            }
+            in = aout;
+        }
+        const float* a = c[0];
+        for (int i = L - 1; i >= 0; i--) {  // inverse_swt's level loop
+            float* out = (i == 0) ? d_images[b] : ((i & 1) ? t2 : t1);
+            const void* e5[5] = {a, c[3 * i + 1], c[3 * i + 2], c[3 * i + 3], out};
+            for (int k = 0; k < 5; k++) {
+                if (!al(e5[k]) || (k < 4 && e5[k] == e5[4])) {
+                    delete B;
+                    return nullptr;
+                }
+                hi[((size_t)i * nimg + b) * 5 + k] = (unsigned long long)(uintptr_t)e5[k];
+            }
+            a = out;
+        }
+    }
+    const size_t bytes = hf.size() * sizeof(unsigned long long);
+    B->d_fwd = (unsigned long long*)pdwt_malloc(bytes);
+    B->d_inv = (unsigned long long*)pdwt_malloc(bytes);
+    if (!B->d_fwd || !B->d_inv || pdwt_memcpy_h2d(B->d_fwd, hf.data(), bytes) != PDWT_OK || pdwt_memcpy_h2d(B->d_inv, hi.data(), bytes) != PDWT_OK) {
+        pdwt_free(B->d_fwd);
+        pdwt_free(B->d_inv);
+        delete B;
+        return nullptr;
+    }
+    return B;
+}
+int swt_batch_forward_f32(void* batch, const pdwt_filters_f32* filt)
+{
+    SwtBatch* B = (SwtBatch*)batch;
+    if (!B || !filt || filt->hlen != B->hlen) return PDWT_EINVAL;
+    const Taps2<float> f = taps_fwd<float>(filt);
+    for (int lev = 0; lev < B->L; lev++) {
+        const int rc = swt_fwd_fused_f32(nullptr, nullptr, nullptr, nullptr, nullptr, B->Nr, B->Nc, B->hlen, 1 << lev, f, B->d_fwd + (size_t)lev * B->nimg * 5, B->nimg);
+        if (rc != PDWT_OK) return rc < 0 ? rc : PDWT_EINVAL;  // (forward reads the images, which are intact: the caller may redo the batch image by image)
+    }
+    return PDWT_OK;
+}
+int swt_batch_inverse_f32(void* batch, const pdwt_filters_f32* filt)
+{
+    SwtBatch* B = (SwtBatch*)batch;
+    if (!B || !filt || filt->hlen != B->hlen) return PDWT_EINVAL;
+    const Taps2<float> f = taps_inv<float>(filt, 0.5f);
+    for (int i = B->L - 1; i >= 0; i--) {
+        const int rc = swt_inv_fused_f32(nullptr, nullptr, nullptr, nullptr, nullptr, B->Nr, B->Nc, B->hlen, 1 << i, f, B->d_inv + (size_t)i * B->nimg * 5, B->nimg);
+        if (rc != PDWT_OK) return rc < 0 ? rc : PDWT_EINVAL;  // (the fused inverse never writes a band: the caller may redo the batch image by image)
+    }
+    return PDWT_OK;
+}
+void swt_batch_destroy_f32(void* batch)
+{
+    SwtBatch* B = (SwtBatch*)batch;
+    if (!B) return;
+    pdwt_free(B->d_fwd);
+    pdwt_free(B->d_inv);
+    delete B;
 }
 
 }  // namespace pdwt

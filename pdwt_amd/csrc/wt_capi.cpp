@@ -69,6 +69,10 @@ void* pdwt_images_new(DTYPE* imgs, int B, int Nr, int Nc, const char* wname, int
 {
     return new (std::nothrow) WaveletsImages(imgs, B, Nr, Nc, wname, levels, memisonhost);
 }
+void* pdwt_images_new_swt(DTYPE* imgs, int B, int Nr, int Nc, const char* wname, int levels, int memisonhost, int do_swt)
+{
+    return new (std::nothrow) WaveletsImages(imgs, B, Nr, Nc, wname, levels, memisonhost, do_swt);
+}
 void pdwt_images_delete(void* h) { delete static_cast<WaveletsImages*>(h); }
 int pdwt_images_ok(void* h) { return static_cast<WaveletsImages*>(h)->ok() ? 1 : 0; }
 int pdwt_images_batched(void* h) { return static_cast<WaveletsImages*>(h)->batched() ? 1 : 0; }

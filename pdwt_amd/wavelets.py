@@ -313,9 +313,10 @@ class ImageBatch:
     """A batch of equally sized 2-D images on one GPU transformed together (include/wt_batch.h: WaveletsImages): every level of ALL
     images runs in one launch when the geometry is inside the streaming level kernels (``batched``), otherwise image after image.
     ``imgs``: array (B, Nr, Nc), numpy (host) or a contiguous device tensor.  ``batch[b]`` is the ordinary ``Wavelets`` view of image
-    b (coefficients, thresholds ... between forward() and inverse()); results equal the per-image transforms bit for bit."""
+    b (coefficients, thresholds ... between forward() and inverse()); results equal the per-image transforms bit for bit.
+    ``do_swt=1``: the undecimated transform (batched in float32 when every level is inside the fused SWT level kernels)."""
 
-    def __init__(self, imgs, wname, levels, dtype=None):
+    def __init__(self, imgs, wname, levels, dtype=None, do_swt=0):
         N.require_gpu()
         dev = _device_source(imgs)
         if dev is not None:
@@ -330,7 +331,7 @@ class ImageBatch:
         assert len(shape) == 3, "imgs must be (B, Nr, Nc)"
         self.dtype, self.shape, self.wname = np.dtype(dt), tuple(int(v) for v in shape), wname
         self._L = N.host(self.dtype)
-        self._h = self._L.pdwt_images_new(src, self.shape[0], self.shape[1], self.shape[2], wname.encode(), int(levels), on_host)
+        self._h = self._L.pdwt_images_new_swt(src, self.shape[0], self.shape[1], self.shape[2], wname.encode(), int(levels), on_host, int(bool(do_swt)))
         if not self._h or not self._L.pdwt_images_ok(self._h):
             raise RuntimeError("ImageBatch creation failed")
 

@@ -1240,6 +1240,9 @@ def test_padded_banks_with_non_finite_samples():
                                   # small levels (64 -> 32 rows), odd sizes, a bank that is zero-padded to the next multiple of 8
                                   (6, 512, 512, "db20", 3, np.float64), (4, 384, 640, "sym8", 3, np.float64), (3, 255, 321, "db4", 2, np.float64),
                                   (5, 256, 256, "db5", 4, np.float64), (3, 64, 64, "db2", 1, np.float64), (3, 2048, 2048, "db20", 2, np.float64),
+                                  # Haar batches through the Haar kernels (gridDim.z = image), both precisions, odd sizes included
+                                  (7, 512, 512, "haar", 4, np.float32), (4, 250, 371, "haar", 3, np.float32), (5, 256, 384, "haar", 3, np.float64),
+                                  (3, 127, 65, "haar", 2, np.float64),
                                   # the cascade kernels with a batch dimension (gridDim.y = image): the C2 geometry (straight-line wave
                                   # programs), a two-level transform, and four levels (the coarsest one on the per-level kernels)
                                   (3, 4096, 4096, "db4", 3, np.float32), (3, 2048, 2048, "db4", 2, np.float32), (3, 2048, 4096, "db2", 4, np.float32)])
@@ -1251,7 +1254,9 @@ def test_image_batch_one_launch_per_level(case):
     B, nr, nc, wname, lev, dt = case
     x = np.random.RandomState(21).uniform(0, 255, (B, nr, nc)).astype(dt)
     IB = pdwt_amd.ImageBatch(x, wname, lev)
-    if dt == np.float32:
+    if wname == "haar":
+        expect_batched = True
+    elif dt == np.float32:
         expect_batched = nr % (4 << (lev - 1)) == 0 and nc % (4 << (lev - 1)) == 0
     else:  # every level at least 16 rows and the padded bank length in either direction
         hp = (IB[0].info.hlen + 7) // 8 * 8
@@ -1287,6 +1292,49 @@ def test_image_batch_one_launch_per_level(case):
     IB.forward()
     IB.inverse()
     assert band_err(IB.get_images()[2], out[2]) <= 10 * tol
+
+
+@pytest.mark.parametrize("case", [(6, 256, 512, "db4", 3, True), (3, 512, 1024, "db7", 4, True), (4, 192, 320, "haar", 2, True), (3, 384, 640, "db10", 2, True),
+                                  (3, 512, 1024, "db16", 3, True), (2, 256, 1000, "db12", 2, True), (3, 100, 130, "db2", 2, False), (3, 120, 256, "sym8", 3, False)])
+def test_image_batch_swt_one_launch_per_level(case):
+    """Round 5: the batched entry on SWT instances (float build): every level of all images in ONE launch of the
+    fused SWT level kernels (gridDim.z = image; swt_fused.inc for banks of up to 20 taps, swt_fused_l2.inc beyond), the approximation
+    ping-ponging through each image's own scratch.  Bit-identical to the per-image transforms; geometries outside the fused kernels
+    (widths that are not a multiple of 4, classes with fewer than 2 hlen rows) run image after image with the same results."""
+    B, nr, nc, wname, lev, expect = case
+    x = np.random.RandomState(23).uniform(0, 255, (B, nr, nc)).astype(np.float32)
+    IB = pdwt_amd.ImageBatch(x, wname, lev, do_swt=1)
+    assert IB[0].info.do_swt == 1 and IB[0].info.nlevels == lev
+    assert IB.batched == expect
+    IB.forward()
+    singles = []
+    for b in range(B):
+        W = pdwt_amd.Wavelets(x[b], wname, lev, do_swt=1)
+        W.forward()
+        singles.append(W)
+        for k, (g, s_) in enumerate(zip(IB[b].coeffs, W.coeffs)):
+            assert np.array_equal(g, s_), (b, "band", k)
+    O = orc.OracleWavelets(x[0], wname, lev, do_swt=1)
+    O.forward()
+    for g, o in zip(IB[0].coeffs, O.coeffs):
+        assert band_err(g, o) <= 1e-5
+    IB.inverse()
+    out = IB.get_images()
+    for b in range(B):
+        singles[b].inverse()
+        assert np.array_equal(out[b], singles[b].get_image()), b
+    assert band_err(out[0], x[0]) <= 1e-5
+    IB.forward()
+    IB.inverse()
+    assert band_err(IB.get_images()[B - 1], out[B - 1]) <= 1e-4
+    # the double build keeps the per-image loop for the SWT (and gives the per-image results)
+    xd = x[:2, :64, :64].astype(np.float64)
+    ID = pdwt_amd.ImageBatch(xd, "db2", 2, do_swt=1)
+    assert not ID.batched
+    ID.forward()
+    Wd = pdwt_amd.Wavelets(xd[1], "db2", 2, do_swt=1)
+    Wd.forward()
+    assert all(np.array_equal(g, s_) for g, s_ in zip(ID[1].coeffs, Wd.coeffs))
 
 
 def test_norm1_in_two_halves_and_clock_probe():
