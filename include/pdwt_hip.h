@@ -122,7 +122,8 @@ int pdwt_batch2d_inverse_f32(void* batch, const pdwt_filters_f32* f);
 void pdwt_batch2d_destroy(void* batch);
 /* the same in double precision (libpdwtd): every level of all images in one launch of the fused double-precision level kernels; any even
  * bank of up to 40 taps, odd sizes included, every level at least 16 rows and the (padded) bank length in either direction; NULL otherwise.
- * The object of the _f64 create goes to the _f64 forward / inverse / destroy. */
+ * The object of the _f64 create goes to the _f64 forward / inverse; a handle of the other precision is refused with PDWT_EINVAL (every
+ * handle carries its kind).  Either destroy releases any handle. */
 void* pdwt_batch2d_create_f64(int nimg, double* const* d_images, double** const* d_coeffs, double* const* d_tmps, pdwt_info info);
 int pdwt_batch2d_forward_f64(void* batch, const pdwt_filters_f64* f);
 int pdwt_batch2d_inverse_f64(void* batch, const pdwt_filters_f64* f);

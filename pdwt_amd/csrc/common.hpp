@@ -163,6 +163,7 @@ enum KnobId {
     KN_EXP1,
     KN_EXP2,
     KN_EXP3,
+    KN_NONSEP_TILED,       // custom non-separable banks (nonsep.hip): 1 = LDS-tiled kernels for levels that fill the chip, 0 = one-thread-per-output kernels, 2 = tiled at every size
     KN_COUNT
 };
 int knob(KnobId id);

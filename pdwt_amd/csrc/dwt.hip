@@ -859,8 +859,8 @@ void* swt_batch_create_f32(int nimg, float* const* d_images, float** const* d_co
 int swt_batch_forward_f32(void* batch, const pdwt_filters_f32* filt);
 int swt_batch_inverse_f32(void* batch, const pdwt_filters_f32* filt);
 void swt_batch_destroy_f32(void* batch);
-struct BatchHaar {  // (kind 2: Haar; kind 3: float32 SWT -- hb is the object of haar.hip / swt.hip)
-    int kind, dev;
+struct BatchHaar {  // (kind 2: Haar; kind 3: float32 SWT -- hb is the object of haar.hip / swt.hip; elem = sizeof of the sample type it was built for)
+    int kind, dev, elem;
     void* hb;
 };
 static void* batch_swt_create(int nimg, float* const* d_images, float** const* d_coeffs, float* const* d_tmps, pdwt_info w)
@@ -868,6 +868,7 @@ static void* batch_swt_create(int nimg, float* const* d_images, float** const* d
     BatchHaar* B = new (std::nothrow) BatchHaar();
     if (!B) return nullptr;
     B->kind = 3;
+    B->elem = 4;
     B->hb = (hipGetDevice(&B->dev) == hipSuccess) ? swt_batch_create_f32(nimg, d_images, d_coeffs, d_tmps, w) : nullptr;
     if (!B->hb) {
         delete B;
@@ -881,6 +882,7 @@ static void* batch_haar_create(int nimg, T* const* d_images, T** const* d_coeffs
     BatchHaar* B = new (std::nothrow) BatchHaar();
     if (!B) return nullptr;
     B->kind = 2;
+    B->elem = (int)sizeof(T);
     B->hb = (hipGetDevice(&B->dev) == hipSuccess) ? haar_batch_create<T>(nimg, d_images, d_coeffs, d_tmps, w) : nullptr;
     if (!B->hb) {
         delete B;
@@ -1206,34 +1208,34 @@ void* pdwt_batch2d_create_f64(int nimg, double* const* d_images, double** const*
     if (batch_is_haar(info)) return batch_haar_create<double>(nimg, d_images, d_coeffs, d_tmps, info);
     return batch2d_create_f64(nimg, d_images, d_coeffs, d_tmps, info);
 }
+// (a handle is only good for the precision it was created in: every entry checks the kind -- and, for the Haar object, the sample size --
+//  before it casts; the other precision's handle is PDWT_EINVAL, not a reinterpretation)
+static int batch_kind(const void* batch, int elem)
+{
+    if (!batch) return -1;
+    const int k = *(const int*)batch;
+    if (k == 0 || k == 3) return elem == 4 ? k : -1;
+    if (k == 1) return elem == 8 ? k : -1;
+    if (k == 2) return ((const BatchHaar*)batch)->elem == elem ? k : -1;
+    return -1;
+}
 int pdwt_batch2d_forward_f64(void* batch, const pdwt_filters_f64* f)
 {
-    if (batch && *(const int*)batch == 2) {
+    const int k = batch_kind(batch, 8);
+    if (k == 2) {
         Batch2DDev on_dev(((BatchHaar*)batch)->dev);
         return haar_batch_forward<double>(((BatchHaar*)batch)->hb);
     }
-    return batch2d_forward_f64((Batch2D64*)batch, f);
+    return k == 1 ? batch2d_forward_f64((Batch2D64*)batch, f) : PDWT_EINVAL;
 }
 int pdwt_batch2d_inverse_f64(void* batch, const pdwt_filters_f64* f)
 {
-    if (batch && *(const int*)batch == 2) {
+    const int k = batch_kind(batch, 8);
+    if (k == 2) {
         Batch2DDev on_dev(((BatchHaar*)batch)->dev);
         return haar_batch_inverse<double>(((BatchHaar*)batch)->hb);
     }
-    return batch2d_inverse_f64((Batch2D64*)batch, f);
-}
-void pdwt_batch2d_destroy_f64(void* batch)
-{
-    if (batch && *(const int*)batch == 2) {
-        haar_batch_destroy<double>(((BatchHaar*)batch)->hb);
-        delete (BatchHaar*)batch;
-        return;
-    }
-    Batch2D64* B = (Batch2D64*)batch;
-    if (!B) return;
-    pdwt_free(B->d_fwd);
-    pdwt_free(B->d_inv);
-    delete B;
+    return k == 1 ? batch2d_inverse_f64((Batch2D64*)batch, f) : PDWT_EINVAL;
 }
 void* pdwt_batch2d_create_f32(int nimg, float* const* d_images, float** const* d_coeffs, float* const* d_tmps, pdwt_info info)
 {
@@ -1243,48 +1245,51 @@ void* pdwt_batch2d_create_f32(int nimg, float* const* d_images, float** const* d
 }
 int pdwt_batch2d_forward_f32(void* batch, const pdwt_filters_f32* f)
 {
-    if (batch && *(const int*)batch == 2) {
+    const int k = batch_kind(batch, 4);
+    if (k == 2 || k == 3) {
         Batch2DDev on_dev(((BatchHaar*)batch)->dev);
-        return haar_batch_forward<float>(((BatchHaar*)batch)->hb);
+        return k == 2 ? haar_batch_forward<float>(((BatchHaar*)batch)->hb) : swt_batch_forward_f32(((BatchHaar*)batch)->hb, f);
     }
-    if (batch && *(const int*)batch == 3) {
-        Batch2DDev on_dev(((BatchHaar*)batch)->dev);
-        return swt_batch_forward_f32(((BatchHaar*)batch)->hb, f);
-    }
-    return batch2d_forward((Batch2D*)batch, f);
+    return k == 0 ? batch2d_forward((Batch2D*)batch, f) : PDWT_EINVAL;
 }
 int pdwt_batch2d_inverse_f32(void* batch, const pdwt_filters_f32* f)
 {
-    if (batch && *(const int*)batch == 2) {
+    const int k = batch_kind(batch, 4);
+    if (k == 2 || k == 3) {
         Batch2DDev on_dev(((BatchHaar*)batch)->dev);
-        return haar_batch_inverse<float>(((BatchHaar*)batch)->hb);
+        return k == 2 ? haar_batch_inverse<float>(((BatchHaar*)batch)->hb) : swt_batch_inverse_f32(((BatchHaar*)batch)->hb, f);
     }
-    if (batch && *(const int*)batch == 3) {
-        Batch2DDev on_dev(((BatchHaar*)batch)->dev);
-        return swt_batch_inverse_f32(((BatchHaar*)batch)->hb, f);
-    }
-    return batch2d_inverse((Batch2D*)batch, f);
+    return k == 0 ? batch2d_inverse((Batch2D*)batch, f) : PDWT_EINVAL;
 }
+// (one destructor for every kind: pdwt_batch2d_destroy and pdwt_batch2d_destroy_f64 are the same function under two names)
 void pdwt_batch2d_destroy(void* batch)
 {
-    if (batch && *(const int*)batch == 2) {
-        haar_batch_destroy<float>(((BatchHaar*)batch)->hb);
-        delete (BatchHaar*)batch;
-        return;
+    if (!batch) return;
+    const int k = *(const int*)batch;
+    if (k == 2 || k == 3) {
+        BatchHaar* H = (BatchHaar*)batch;
+        if (k == 3)
+            swt_batch_destroy_f32(H->hb);
+        else if (H->elem == 8)
+            haar_batch_destroy<double>(H->hb);
+        else
+            haar_batch_destroy<float>(H->hb);
+        delete H;
+    } else if (k == 1) {
+        Batch2D64* B = (Batch2D64*)batch;
+        pdwt_free(B->d_fwd);
+        pdwt_free(B->d_inv);
+        delete B;
+    } else if (k == 0) {
+        Batch2D* B = (Batch2D*)batch;
+        pdwt_free(B->d_fwd);
+        pdwt_free(B->d_inv);
+        pdwt_free(B->d_cf);
+        pdwt_free(B->d_ci);
+        delete B;
     }
-    if (batch && *(const int*)batch == 3) {
-        swt_batch_destroy_f32(((BatchHaar*)batch)->hb);
-        delete (BatchHaar*)batch;
-        return;
-    }
-    Batch2D* B = (Batch2D*)batch;
-    if (!B) return;
-    pdwt_free(B->d_fwd);
-    pdwt_free(B->d_inv);
-    pdwt_free(B->d_cf);
-    pdwt_free(B->d_ci);
-    delete B;
 }
+void pdwt_batch2d_destroy_f64(void* batch) { pdwt_batch2d_destroy(batch); }
 int pdwt_debug_set(const char* key, int value) { return pdwt::knob_set(key, value); }
 int pdwt_debug_get(const char* key, int* value) { return pdwt::knob_get(key, value); }
 size_t pdwt_tmp_elems(pdwt_info w) { return 2 * (size_t)(w.Nr > 0 ? w.Nr : 0) * (size_t)(w.Nc > 0 ? w.Nc : 0) + 1024; }

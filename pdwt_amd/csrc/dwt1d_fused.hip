@@ -79,6 +79,30 @@ struct Fwd1DGeom {
 // (measured: 78 % of wave cycles in SQ_WAIT_ANY).  LDS hand-offs only need this wave's DS operations retired.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Cache policy of the row traffic (every row is read once and written once).  PDWT_1D_NT: bit 0 = non-temporal row loads in the forward
+// kernels, bit 2 = non-temporal band loads in the inverse kernels, bit 1 = non-temporal band / row stores.  Measured on the C4 shape
+// (docs/EXPERIMENTS.md, round 5); the default is what won.
+#ifndef PDWT_1D_NT
+#define PDWT_1D_NT 0
+#endif
+template <int BIT, typename V>
+__device__ __forceinline__ V ld_row(const V* p)
+{
+    if constexpr ((PDWT_1D_NT & BIT) != 0)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
+}
+template <typename V>
+__device__ __forceinline__ void st_row(V* p, const V& v)
+{
+#if PDWT_1D_NT & 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // LDS bank swizzle.  A work item's window is WL/NV consecutive 16-byte slots and consecutive lanes start two
 // slots apart, so for one ds_read_b128 the lanes of a service group hit every slot of the 256-byte bank row
 // twice (measured: SQ_LDS_BANK_CONFLICT = 80 % of SQ_LDS_IDX_ACTIVE).  XOR-ing bit 0 of the slot index with
@@ -130,7 +154,7 @@ __global__ __launch_bounds__(256) void k_fwd1d_fused(const T* __restrict__ in, B
         const V* src_ = reinterpret_cast<const V*>(in + (size_t)(ROW) * (size_t)Nc);                            \
         sfor<kPre1D>([&](auto K_) {                                                                            \
             constexpr int k_ = decltype(K_)::value;                                                            \
-            pre[k_] = src_[min((int)threadIdx.x + 256 * k_, nchunks - 1)];                                     \
+            pre[k_] = ld_row<1>(src_ + min((int)threadIdx.x + 256 * k_, nchunks - 1));                                     \
         });                                                                                                    \
     }
     // branch-free (index clamped, not predicated): a conditional load makes hipcc wait for each one at the join;
@@ -218,8 +242,8 @@ __global__ __launch_bounds__(256) void k_fwd1d_fused(const T* __restrict__ in, B
                     }
                 }
                 if (vec_ok) {  // wave-uniform
-                    *reinterpret_cast<V*>(gd + i0) = vhi;
-                    if (last) *reinterpret_cast<V*>(ga + i0) = vlo;
+                    st_row(reinterpret_cast<V*>(gd + i0), vhi);
+                    if (last) st_row(reinterpret_cast<V*>(ga + i0), vlo);
                 } else {
 #pragma unroll
                     for (int q = 0; q < PO; q++)
@@ -280,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd1d_fused_ip(const T* __restrict__
         asm volatile("" : "+v"(tx_));                                                                          \
         sfor<KPRE>([&](auto K_) {                                                                              \
             constexpr int k_ = decltype(K_)::value;                                                            \
-            pre[k_] = src_[min(tx_ + 256 * k_, nchunks - 1)];                                                  \
+            pre[k_] = ld_row<1>(src_ + min(tx_ + 256 * k_, nchunks - 1));                                             \
         });                                                                                                    \
     }
     size_t row = blockIdx.x;
@@ -332,8 +356,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd1d_fused_ip(const T* __restrict__
                         vhi[q] = h;
                     }
                     if (vec_ok) {
-                        *reinterpret_cast<V*>(gd + i0) = vhi;
-                        if (last) *reinterpret_cast<V*>(ga + i0) = vlo;
+                        st_row(reinterpret_cast<V*>(gd + i0), vhi);
+                        if (last) st_row(reinterpret_cast<V*>(ga + i0), vlo);
                     } else {
 #pragma unroll
                         for (int q = 0; q < PO; q++)
@@ -465,6 +489,20 @@ __device__ __forceinline__ void inv1d_store(T* dst, int g0, int nout, bool vec_o
     }
 }
 
+template <typename T, int NV2, typename V>
+__device__ __forceinline__ void inv1d_store_g(T* dst, int g0, int nout, bool vec_ok, const V (&res)[2])  // (to the output row in global memory)
+{
+    constexpr int NV = NV2;
+    if (vec_ok && g0 + 2 * NV <= nout) {
+        st_row(reinterpret_cast<V*>(dst + g0), res[0]);
+        st_row(reinterpret_cast<V*>(dst + g0) + 1, res[1]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2 * NV; q++)
+            if (g0 + q < nout) dst[g0 + q] = res[q / NV][q % NV];
+    }
+}
+
 template <typename T, int HLEN>
 __global__ __launch_bounds__(256) void k_inv1d_fused(T* __restrict__ out_img, Bands1D<T> b, Taps2<T> f)
 {
@@ -507,7 +545,7 @@ __global__ __launch_bounds__(256) void k_inv1d_fused(T* __restrict__ out_img, Ba
         for (int it = threadIdx.x; it < items; it += 256) {
             V res[2];
             inv1d_item<T, HLEN>(a, sd, it, f, res);
-            if (last) inv1d_store<T, NV, V>(g, it * PO, nout, vec_ok, res);
+            if (last) inv1d_store_g<T, NV, V>(g, it * PO, nout, vec_ok, res);
             else inv1d_store<T, NV, V>(o, it * PO, nout + HR - PO, true, res);  // spill of a partial item lands in halo cells (refilled)
         }
         if (last) break;
@@ -559,7 +597,7 @@ __global__ __launch_bounds__(256) void k_inv1d_fused_pf(T* __restrict__ out_img,
         const V* src_ = reinterpret_cast<const V*>(b.p[lc_] + (size_t)(ROW) * (size_t)n_);            \
         sfor<inv_cap(lv_)>([&](auto K_) {                                                              \
             constexpr int k_ = decltype(K_)::value;                                                    \
-            pre[inv_slot0(lv_) + k_] = src_[min((int)threadIdx.x + 256 * k_, n_ / NV - 1)];            \
+            pre[inv_slot0(lv_) + k_] = ld_row<4>(src_ + min((int)threadIdx.x + 256 * k_, n_ / NV - 1));            \
         });                                                                                            \
     });
 
@@ -595,7 +633,7 @@ __global__ __launch_bounds__(256) void k_inv1d_fused_pf(T* __restrict__ out_img,
                 for (int it = threadIdx.x; it < items; it += 256) {
                     V res[2];
                     inv1d_item<T, HLEN>(a, sd, it, f, res);
-                    if (last) inv1d_store<T, NV, V>(g, it * PO, nout, vec_ok, res);
+                    if (last) inv1d_store_g<T, NV, V>(g, it * PO, nout, vec_ok, res);
                     else inv1d_store<T, NV, V>(o, it * PO, nout + HR - PO, true, res);
                 }
                 lds_barrier();
@@ -641,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void k_inv1d_fused_ip(T* __restrict__ out_i
         const V* src_ = reinterpret_cast<const V*>(b.p[lc_] + (size_t)(ROW) * (size_t)n_);            \
         sfor<inv_cap_x<CAP>(lv_)>([&](auto K_) {                                                       \
             constexpr int k_ = decltype(K_)::value;                                                    \
-            pre[inv_slot0_x<CAP>(lv_) + k_] = src_[min((int)threadIdx.x + 256 * k_, n_ / NV - 1)];     \
+            pre[inv_slot0_x<CAP>(lv_) + k_] = ld_row<4>(src_ + min((int)threadIdx.x + 256 * k_, n_ / NV - 1));     \
         });                                                                                            \
     });
 
@@ -676,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void k_inv1d_fused_ip(T* __restrict__ out_i
                     for (int it = threadIdx.x; it < items; it += 256) {
                         V res[2];
                         inv1d_item<T, HLEN>(a, sd, it, f, res);
-                        inv1d_store<T, NV, V>(g, it * PO, nout, vec_ok, res);
+                        inv1d_store_g<T, NV, V>(g, it * PO, nout, vec_ok, res);
                     }
                     lds_barrier();  // (the next row's A_L overwrites `a`)
                 } else {

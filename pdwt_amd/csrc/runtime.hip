@@ -76,7 +76,7 @@ static const KnobDef g_knob_defs[KN_COUNT] = {
     {"f64_lds", "PDWT_F64_LDS", 1}, {"f64_lds_min", "PDWT_F64_LDS_MIN", 256}, {"f64_lds_wgs", "PDWT_F64_LDS_WGS", 512}, {"f64_lds_mingroups", "PDWT_F64_LDS_MINGROUPS", 1}, {"f64_lds_skew", "PDWT_F64_LDS_SKEW", 64}, {"norm2sq_ref1d", "PDWT_NORM2SQ_REF1D", 0},
     {"norm_in_threshold", "PDWT_NORM_IN_THRESHOLD", -1},
     {"selfcheck", "PDWT_SELFCHECK", 1}, {"dwt1d_f64", "PDWT_DWT1D_F64", 1}, {"swtf_long", "PDWT_SWTF_LONG", 1}, {"f64_tail", "PDWT_F64_TAIL", 0},
-    {"exp0", "PDWT_EXP0", 0}, {"exp1", "PDWT_EXP1", 0}, {"exp2", "PDWT_EXP2", 0}, {"exp3", "PDWT_EXP3", 0},
+    {"exp0", "PDWT_EXP0", 0}, {"exp1", "PDWT_EXP1", 0}, {"exp2", "PDWT_EXP2", 0}, {"exp3", "PDWT_EXP3", 0}, {"nonsep_tiled", "PDWT_NONSEP_TILED", 1},
 };
 static int g_knob_vals[KN_COUNT];
 static std::once_flag g_knob_once;

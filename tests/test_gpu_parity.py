@@ -1510,3 +1510,91 @@ def test_cascade_wave_programs_geometries():
             outs.append((c, W.get_image()))
     for o in outs[1:]:
         assert all(np.array_equal(a, b) for a, b in zip(outs[0][0], o[0])) and np.array_equal(outs[0][1], o[1])
+
+
+@pytest.mark.gpu
+def test_batch2d_handles_are_bound_to_their_precision():
+    """include/pdwt_hip.h pdwt_batch2d_*: a handle created in one precision is refused (PDWT_EINVAL, nothing launched) by the other
+    precision's forward / inverse, for the Haar object (one struct for both precisions) and the filter-bank objects alike; either destroy
+    releases any handle."""
+    import ctypes as C
+    from pdwt_amd import _native as nat
+    L = nat.hip()
+    EINVAL = -1
+    made = []
+
+    def make(sfx, ct, hlen, n=256):
+        info = nat.Info(2, n, n, 1, 0, hlen)
+        imgs, tmps, cfs = [], [], []
+        for _ in range(2):
+            imgs.append(L.pdwt_malloc(n * n * C.sizeof(ct)))
+            tmps.append(L.pdwt_malloc(L.pdwt_tmp_elems(info) * C.sizeof(ct)))
+            cfs.append(getattr(L, "pdwt_create_coeffs_buffer_" + sfx)(info))
+            L.pdwt_memset(imgs[-1], 0, n * n * C.sizeof(ct))
+        ai = (C.c_void_p * 2)(*imgs)
+        at = (C.c_void_p * 2)(*tmps)
+        ac = (C.c_void_p * 2)(*[C.cast(c, C.c_void_p) for c in cfs])
+        h = getattr(L, "pdwt_batch2d_create_" + sfx)(2, ai, ac, at, info)
+        made.append((sfx, info, imgs, tmps, cfs))
+        return h
+
+    FT = {"f32": nat.Filters32, "f64": nat.Filters64}
+    filt = {}
+    for sfx in ("f32", "f64"):
+        filt[sfx] = FT[sfx]()
+        assert getattr(L, "pdwt_compute_filters_separable_" + sfx)(b"db4", 0, C.byref(filt[sfx])) == 8
+    try:
+        for hlen in (2, 8):
+            h32 = make("f32", C.c_float, hlen)
+            h64 = make("f64", C.c_double, hlen)
+            assert h32 and h64
+            assert L.pdwt_batch2d_forward_f64(h32, C.byref(filt["f64"])) == EINVAL
+            assert L.pdwt_batch2d_inverse_f64(h32, C.byref(filt["f64"])) == EINVAL
+            assert L.pdwt_batch2d_forward_f32(h64, C.byref(filt["f32"])) == EINVAL
+            assert L.pdwt_batch2d_inverse_f32(h64, C.byref(filt["f32"])) == EINVAL
+            assert L.pdwt_batch2d_forward_f32(h32, C.byref(filt["f32"])) == 0
+            assert L.pdwt_batch2d_forward_f64(h64, C.byref(filt["f64"])) == 0
+            L.pdwt_sync()
+            L.pdwt_batch2d_destroy_f64(h32)  # (either destroy, any handle)
+            L.pdwt_batch2d_destroy(h64)
+        assert L.pdwt_batch2d_forward_f32(None, C.byref(filt["f32"])) == EINVAL
+    finally:
+        L.pdwt_sync()
+        for sfx, info, imgs, tmps, cfs in made:
+            for p in imgs + tmps:
+                L.pdwt_free(p)
+            for c in cfs:
+                getattr(L, "pdwt_free_coeffs_buffer_" + sfx)(c, info)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("case", [((512, 768), 8, 3, 0), ((257, 391), 5, 2, 0), ((300, 260), 6, 2, 0), ((96, 1100), 3, 2, 0), ((128, 128), 2, 3, 0),
+                                  ((192, 160), 13, 2, 0), ((320, 448), 24, 1, 0), ((256, 384), 40, 1, 0), ((64, 64), 1, 1, 0),
+                                  ((256, 384), 4, 4, 1), ((128, 256), 7, 3, 1), ((512, 512), 8, 5, 1), ((96, 96), 16, 3, 1),
+                                  ((2048, 2048), 6, 3, 0), ((2048, 1024), 4, 2, 1)])
+def test_nonseparable_tiled_kernels_equal_the_plain_ones(case, dt):
+    """nonsep.hip: the LDS-tiled kernels (default) against the one-thread-per-output kernels (knob nonsep_tiled = 0) -- same taps in the
+    same order, one FMA each: every band and the reconstruction bit for bit; sizes with partial tiles, odd sizes (replicated last sample),
+    odd and long kernels, one- and two-row forms, SWT levels whose tiles fall back to the plain kernel (dilation x kernel too large for LDS).
+    The plain kernels are pinned to the oracle and to the independent direct sums above."""
+    shape, n, levels, swt = case
+    rs = np.random.RandomState(62 + n)
+    kf = [rs.randn(n, n) for _ in range(4)]
+    ki = [rs.randn(n, n) for _ in range(4)]
+    x = rs.uniform(-10, 10, shape).astype(dt)
+    res = []
+    for tiled in ((1 if shape[0] >= 2048 else 2), 0):  # (1 = the default: tiled where a level fills the chip; 2 = tiled at every size)
+        with knobs(nonsep_tiled=tiled):
+            W = pdwt_amd.Wavelets(x, "db2", levels, do_separable=0, do_swt=swt)
+            assert W.set_filters_forward_nonseparable("custom2d", *kf) == 0
+            assert W.set_filters_inverse_nonseparable(*ki) == 0
+            W.forward()
+            c = W.coeffs
+            W.inverse()
+            res.append((W.info.nlevels, c, W.get_image()))
+    assert res[0][0] == res[1][0]
+    for k, (a, b) in enumerate(zip(res[0][1], res[1][1])):
+        assert np.array_equal(a, b), (case, k, float(np.abs(a.astype(np.float64) - b).max()))
+    assert np.array_equal(res[0][2], res[1][2]), (case, float(np.abs(res[0][2].astype(np.float64) - res[1][2]).max()))
+    assert np.isfinite(res[0][2]).all()
