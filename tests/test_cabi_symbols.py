@@ -126,3 +126,26 @@ def test_rccl_abi_constants_match_the_header_when_present():
             "ncclComm_t comm, hipStream_t stream);") in flat
     assert "ncclResult_t ncclCommDestroy(ncclComm_t comm);" in flat
     assert "ncclResult_t ncclGroupStart();" in flat and "ncclResult_t ncclGroupEnd();" in flat
+
+
+def test_every_run_time_switch_is_documented_and_readable_without_a_gpu():
+    """pdwt_debug_get / pdwt_debug_set (include/pdwt_hip.h): every knob of the table in runtime.hip answers on a box without a GPU (the
+    table is host state, read from the environment once) and has its row in INTEGRATION.md section E; an unknown key is PDWT_EINVAL."""
+    src = open(os.path.join(ROOT, "pdwt_amd", "csrc", "runtime.hip")).read()
+    table = re.findall(r'\{"([a-z0-9_]+)",\s*"(PDWT_[A-Z0-9_]+)",\s*(-?\d+)\}', src)
+    assert len(table) >= 40
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    L = pdwt_amd.hip()
+    for key, env, default in table:
+        v = C.c_int(-12345)
+        assert L.pdwt_debug_get(key.encode(), C.byref(v)) == 0, key
+        if env not in os.environ:
+            assert v.value == int(default), (key, v.value, default)
+        assert "`%s`" % key in doc, "knob %s has no row in INTEGRATION.md section E" % key
+        assert env == "PDWT_" + key.upper(), (key, env)
+    v = C.c_int(0)
+    assert L.pdwt_debug_get(b"no_such_knob", C.byref(v)) == -1
+    assert L.pdwt_debug_set(b"no_such_knob", 1) == -1
+    # a set is visible to the next get, and restoring it leaves the table as it was
+    assert L.pdwt_debug_set(b"nonsep_tiled", 0) == 0 and L.pdwt_debug_get(b"nonsep_tiled", C.byref(v)) == 0 and v.value == 0
+    assert L.pdwt_debug_set(b"nonsep_tiled", 1) == 0
