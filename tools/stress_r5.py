@@ -2,7 +2,8 @@
 """Randomised bit-exactness sweep of the kernels added in round 5 against the kernels they replace (knob off):
   * batched 1-D in double precision, rows whose two-buffer footprint exceeds the LDS budget (dwt1d_f64),
   * fused SWT levels for float32 banks of 22 ... 40 taps (swtf_long; inverse: 1e-5),
-  * the batched 2-D entry in double precision against per-image transforms.
+  * the batched 2-D entry in double precision against per-image transforms,
+  * the LDS-tiled kernels of custom non-separable banks (nonsep_tiled = 2) against the one-thread-per-output kernels.
 usage: PYTHONPATH=. python tools/stress_r5.py [n] [seed]"""
 import ctypes as C
 import sys
@@ -93,5 +94,31 @@ for it in range(max(4, n // 2)):
     if not ok:
         bad += 1
         print("MISMATCH batch f64", B, nr, nc, wname, lev, IB.batched)
+for it in range(n):
+    # ---- custom non-separable banks: LDS-tiled kernels (every size: knob 2) against the one-thread-per-output kernels
+    dt = (np.float32, np.float64)[rs.randint(2)]
+    swt = int(rs.randint(3) == 0)
+    hl = int(rs.randint(1, 41)) if rs.randint(4) == 0 else int(rs.randint(1, 13))
+    nr, nc = int(rs.randint(hl + 8, 700)), int(rs.randint(hl + 8, 900))
+    if swt:
+        nr, nc = (nr + 7) // 8 * 8, (nc + 7) // 8 * 8
+    lev = int(rs.randint(1, 4))
+    kf = [rs.randn(hl, hl) for _ in range(4)]
+    ki = [rs.randn(hl, hl) for _ in range(4)]
+    x = rs.uniform(-5, 5, (nr, nc)).astype(dt)
+    res = []
+    for tiled in (2, 0):
+        knob("nonsep_tiled", tiled)
+        W = pdwt_amd.Wavelets(x, "db2", lev, do_separable=0, do_swt=swt)
+        assert W.set_filters_forward_nonseparable("custom2d", *kf) == 0 and W.set_filters_inverse_nonseparable(*ki) == 0
+        W.forward()
+        c = W.coeffs
+        W.inverse()
+        res.append((c, W.get_image(), W.info.nlevels))
+    knob("nonsep_tiled", 1)
+    ok = res[0][2] == res[1][2] and all(np.array_equal(a, b) for a, b in zip(res[0][0], res[1][0])) and np.array_equal(res[0][1], res[1][1])
+    if not ok:
+        bad += 1
+        print("MISMATCH nonsep", np.dtype(dt).name, swt, hl, nr, nc, lev)
 print("stress_r5: %d cases per family, %d mismatches" % (n, bad))
 sys.exit(1 if bad else 0)
