@@ -352,6 +352,20 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
     wall1 = time.time()
     gpu_ms = L.pdwt_event_elapsed_ms(e0, e1)
     power = _SAMPLER.window(wall0, wall1) if _SAMPLER is not None else None
+    # A short timed region (the driver runs `--steps 20 --warmup 5`: 1 ms of C2) carries the bracket itself -- first launch on an idle GPU,
+    # wake-up of the final synchronize: ~25 us, 1.2 us per step at K = 20 (tools/k20_probe.py) -- and a cold start of the caches.  The
+    # contract's number stays `ms_per_step`; what the same loop costs per step once that is amortised is reported NEXT to it (untimed for
+    # `value`): `steady_state` = the same step repeated until >= 0.1 s of GPU work, bracketed the same way.
+    steady = None
+    if world == 1 and elapsed < 0.05:
+        n_long = max(200, min(5000, int(0.1 / max(elapsed / steps, 1e-6))))
+        sync()
+        t0s = time.perf_counter()
+        for _ in range(n_long):
+            step()
+        sync()
+        steady = {"steps": n_long, "ms_per_step": round((time.perf_counter() - t0s) / n_long * 1e3, 5),
+                  "what": "the same step, same bracket, over a region long enough to amortise the bracket (first launch on an idle GPU + synchronize wake-up) and the cold start; not used for `value`"}
     if world > 1:
         t = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -578,7 +592,7 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
     return {"value": round(value, 1), "unit": cfg["unit"], "ms_per_step": round(ms_per_step, 5), "gpu_ms_per_step": round(gpu_ms / steps, 5),
             "steps": steps, "warmup": warmup, "levels": levels_eff, "workload": cfg["desc"], "dtype": "f32" if cfg["dtype"] == "float32" else "f64",
             "sanity": sanity, "roundtrip_max_rel_err": rt_err, "roofline": roofline, "cpu_baseline": cpu, "power": power,
-            "images_per_step": nbatch, "ms_per_image_pair": round(ms_per_step / nbatch, 5), "extra_timing": extra_timing, "clock_probe": clock_probe,
+            "images_per_step": nbatch, "ms_per_image_pair": round(ms_per_step / nbatch, 5), "extra_timing": extra_timing, "clock_probe": clock_probe, "steady_state": steady,
             "kernels": {k: {a: round(b, 3) for a, b in v.items()} for k, v in kernels.items()}}
 
 
@@ -795,7 +809,7 @@ def main():
                                        "batch that streams through HBM is other_configs.c2_batch") if args.config == "c2" else None},
             "gpu_ms_per_step": res["gpu_ms_per_step"], "settle_ms": args.settle_ms, "roundtrip_max_rel_err": res["roundtrip_max_rel_err"],
             "sanity": res["sanity"], "roofline": res["roofline"], "cpu_baseline": res["cpu_baseline"], "power": res["power"],
-            "extra_timing": res.get("extra_timing"), "clock_probe": res.get("clock_probe"),
+            "extra_timing": res.get("extra_timing"), "clock_probe": res.get("clock_probe"), "steady_state": res.get("steady_state"),
             "kernels": res["kernels"], "other_configs": others,
             "rccl_ranks": rccl_ranks if coll_backend == "nccl" else None, "collective": {"backend": coll_backend, "ranks": rccl_ranks} if world > 1 else None,
             "per_rank": per_rank,
