@@ -339,19 +339,28 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
     sync()
     barrier()
     sync()
-    e0, e1 = L.pdwt_event_create(), L.pdwt_event_create()
+    # the timed region of the contract: barrier + synchronize on both sides and NOTHING but the K steps inside -- no event markers
+    # (two barrier packets on the queue: +0.16 us per step at K = 20) and one device-wide synchronize, which covers the library's
+    # stream (a stream synchronize in front of it: +0.3 us per step at K = 20; tools/k20_bracket.py)
     wall0 = time.time()
     t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    wall1 = time.time()
+    power = _SAMPLER.window(wall0, wall1) if _SAMPLER is not None else None
+    # the same K steps once more between two HIP events on the library stream: `gpu_ms_per_step` (what the GPU spent between the first
+    # kernel's start and the last one's end, without the bracket)
+    sync()
+    e0, e1 = L.pdwt_event_create(), L.pdwt_event_create()
     L.pdwt_event_record(e0)
     for _ in range(steps):
         step()
     L.pdwt_event_record(e1)
     sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    wall1 = time.time()
     gpu_ms = L.pdwt_event_elapsed_ms(e0, e1)
-    power = _SAMPLER.window(wall0, wall1) if _SAMPLER is not None else None
     # A short timed region (the driver runs `--steps 20 --warmup 5`: 1 ms of C2) carries the bracket itself -- first launch on an idle GPU,
     # wake-up of the final synchronize: ~25 us, 1.2 us per step at K = 20 (tools/k20_probe.py) -- and a cold start of the caches.  The
     # contract's number stays `ms_per_step`; what the same loop costs per step once that is amortised is reported NEXT to it (untimed for
@@ -363,7 +372,7 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
         t0s = time.perf_counter()
         for _ in range(n_long):
             step()
-        sync()
+        torch.cuda.synchronize()
         steady = {"steps": n_long, "ms_per_step": round((time.perf_counter() - t0s) / n_long * 1e3, 5),
                   "what": "the same step, same bracket, over a region long enough to amortise the bracket (first launch on an idle GPU + synchronize wake-up) and the cold start; not used for `value`"}
     if world > 1:
