@@ -4,6 +4,10 @@ import time
 import torch
 import pdwt_amd
 
+import ctypes, os
+if os.environ.get("K20_SCHED"):
+    HIP = ctypes.CDLL("libamdhip64.so")
+    print("hipSetDeviceFlags ->", HIP.hipSetDeviceFlags(int(os.environ["K20_SCHED"])))  # 1 spin, 2 yield, 4 blocking sync
 L = pdwt_amd.hip()
 x = torch.rand((4096, 4096), device="cuda", dtype=torch.float32) * 255
 torch.cuda.synchronize()
