@@ -46,4 +46,6 @@ if echo "$CFGS" | grep -qw c2; then
     PDWT_LIBDIR=$R/pdwt_amd/lib_trace python tools/casc_trace.py --md $OUT/${TAG}_c2_timeline.md > /dev/null 2>&1
   fi
 fi
+# (raw rocprofv3 output stays on the box: gpurun only brings back 64 MiB)
+rm -rf $R/gpurun_out/pmc_${TAG}_* $R/gpurun_out/prof_${TAG}_*
 cd $R; cp profiles/pmc_traffic.json $OUT/pmc_traffic.json; ls $OUT
