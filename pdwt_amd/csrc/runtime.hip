@@ -334,7 +334,7 @@ int pdwt_event_destroy(void* ev)
 // A small multi-level transform is a handful of 4-5 us launches whose cost is the CPU enqueue, not the GPU (512^2 db4
 // L3: 6 launches, 24 us per pair of which < 8 us is kernel time).  The class can record the launches of one forward()
 // or inverse() once and replay them as ONE graph launch (wt.cpp, opt-in: PDWT_GRAPH=1).
-int pdwt_graph_allowed(void) { return g_kt_on ? 0 : 1; }  // per-kernel event timing and capture do not mix
+int pdwt_graph_allowed(void) { return (g_kt_on || g_probe_on) ? 0 : 1; }  // per-kernel event timing / the clock probe (allocates on first use) and capture do not mix
 int pdwt_graph_capture_begin(void)
 {
     PDWT_HIP_TRY(hipStreamBeginCapture(pdwt::stream(), hipStreamCaptureModeThreadLocal));

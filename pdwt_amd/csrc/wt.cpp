@@ -318,9 +318,12 @@ static int run_graphed(void* st, int dir, bool eligible, F enqueue)
         void* exec = NULL;
         const int rc2 = pdwt_graph_capture_end(&exec);
         if (rc != PDWT_OK || rc2 != PDWT_OK) {
+            // Nothing ran while recording.  A launcher's first use may do what a capture refuses (an LDS opt-in of a kernel, an
+            // allocation of the diagnostic probes): the recording failed, not the transform -- plain launches from now on, and the
+            // enqueue itself decides whether there is an error to report.
             if (exec) pdwt_graph_destroy(exec);
             WS(st)->graph_off = 1;
-            return rc != PDWT_OK ? rc : enqueue();
+            return enqueue();
         }
         WS(st)->graph[dir] = exec;
     }
