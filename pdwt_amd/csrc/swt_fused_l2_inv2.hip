@@ -1,0 +1,5 @@
+// swt_fused_l2_inv2.hip -- inverse SWT levels for float32 banks of 22 ... 40 taps with the tap spacing 2 fixed at compile time
+// (swt_fused_l2.inc, part 3)
+#define PDWT_SWTL2_PART 3
+#define PDWT_SWTL2_FSEL 2
+#include "swt_fused_l2.inc"
