@@ -691,11 +691,12 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
                 constexpr int j = decltype(J)::value;
                 constexpr int s = (s0 + j) % H2;
                 constexpr int k = HLEN - 1 - (2 * j + off);
-                const v2f fl = splat(f.a[k]), fh = splat(f.b[k]);
-                sa = pk_fma(ra[s], fl, sa);
-                sh = pk_fma(rh[s], fh, sh);
-                sv = pk_fma(rv[s], fl, sv);
-                sd = pk_fma(rd[s], fh, sd);
+                constexpr int kp = k & ~1;  // tap k as one half of its aligned pair: no splat copies in scalar registers (dwt_stream.hip)
+                const v2f pl2 = v2f{f.a[kp], f.a[kp + 1]}, ph2 = v2f{f.b[kp], f.b[kp + 1]};
+                sa = pk_fma_sbcast<k & 1, false>(ra[s], pl2, sa);
+                sh = pk_fma_sbcast<k & 1, false>(rh[s], ph2, sh);
+                sv = pk_fma_sbcast<k & 1, false>(rv[s], pl2, sv);
+                sd = pk_fma_sbcast<k & 1, false>(rd[s], ph2, sd);
             });
             const v2f t1o = sa + sh, t2o = sv + sd;
             float t1[WIN1], t2[WIN1];
@@ -761,8 +762,9 @@ __global__ __launch_bounds__(256) void k_inv2d_casc(CascInvBands b, float* __res
             constexpr int j = decltype(J)::value;
             constexpr int s = (s0 + j) % H2;
             constexpr int k = HLEN - 1 - (2 * j + off);
-            sav = pk_fma(r2av[s], splat(f.a[k]), sav);
-            shd = pk_fma(r2hd[s], splat(f.b[k]), shd);
+            constexpr int kp = k & ~1;  // tap k as one half of its aligned pair: no splat copies in scalar registers (dwt_stream.hip)
+            sav = pk_fma_sbcast<k & 1, false>(r2av[s], v2f{f.a[kp], f.a[kp + 1]}, sav);
+            shd = pk_fma_sbcast<k & 1, false>(r2hd[s], v2f{f.b[kp], f.b[kp + 1]}, shd);
         });
         const v2f t = sav + shd;  // (t1, t2) of the lane's column
         float t1[WIN2], t2[WIN2];

@@ -295,11 +295,14 @@ __global__ __launch_bounds__(256) void k_inv2d_stream(const float* __restrict__ 
             constexpr int j = decltype(J)::value;
             constexpr int s = (s0 + j) % H2;
             constexpr int k = HLEN - 1 - (2 * j + off);
-            const v2f fl = splat(f.a[k]), fh = splat(f.b[k]);
-            sa = pk_fma(ra[s], fl, sa);
-            sh = pk_fma(rhh[s], fh, sh);
-            sv = pk_fma(rv[s], fl, sv);
-            sd = pk_fma(rd[s], fh, sd);
+            // tap k as one half of the aligned pair it arrives in (pk_fma_sbcast): a splat per tap doubles the scalar registers of the two
+            // banks, and from 12 taps on the compiler parks them in VGPR lanes (k_inv2d_stream<16>: 1374 v_readlane in 10 k instructions)
+            constexpr int kp = k & ~1;
+            const v2f pl2 = v2f{f.a[kp], f.a[kp + 1]}, ph2 = v2f{f.b[kp], f.b[kp + 1]};
+            sa = pk_fma_sbcast<k & 1, false>(ra[s], pl2, sa);
+            sh = pk_fma_sbcast<k & 1, false>(rhh[s], ph2, sh);
+            sv = pk_fma_sbcast<k & 1, false>(rv[s], pl2, sv);
+            sd = pk_fma_sbcast<k & 1, false>(rd[s], ph2, sd);
         });
         const v2f t1o = sa + sh, t2o = sv + sd;
         float t1[WIN], t2[WIN];
