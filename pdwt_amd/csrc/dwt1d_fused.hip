@@ -784,12 +784,12 @@ static int launch_fwd(const T* in, T** c, const pdwt_info& w, const Taps2<T>& f)
     constexpr int NVh = Vec16<T>::N;
     if (lds > lds_budget_1d()) {
         // the one-buffer form (double precision only: float rows of that size are a wash, see lds_budget_1d) when IT fits the budget
-        if constexpr (sizeof(T) == 8) {
+        if constexpr (sizeof(T) == 8 && HLEN <= 20) {  // (longer banks are not instantiated: they would never be launched, see below)
             constexpr int MAXIT = 8, KPRE = 16;
             const size_t lds1 = (size_t)G::buf_elems(w.Nc) * sizeof(T);
             const int items1 = (b.n[1] + G::PO - 1) / G::PO;
             // (banks of more than 20 taps: the window of an item no longer fits next to the prefetch registers -- scratch spills -- per-level kernels)
-            if (HLEN <= 20 && knob(KN_DWT1D_F64) == 1 && w.nlevels > 1 && lds1 <= lds_budget_1d() && items1 <= MAXIT * 256 && (w.Nc % NVh) == 0 && ((uintptr_t)in & 15) == 0 &&
+            if (knob(KN_DWT1D_F64) == 1 && w.nlevels > 1 && lds1 <= lds_budget_1d() && items1 <= MAXIT * 256 && (w.Nc % NVh) == 0 && ((uintptr_t)in & 15) == 0 &&
                 (w.Nc / NVh) <= KPRE * 256) {
                 auto k = k_fwd1d_fused_ip<T, HLEN, MAXIT, KPRE>;
                 if (set_lds(k, lds1) != PDWT_OK) return PDWT_EHIP;
