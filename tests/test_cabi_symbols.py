@@ -149,3 +149,33 @@ def test_every_run_time_switch_is_documented_and_readable_without_a_gpu():
     # a set is visible to the next get, and restoring it leaves the table as it was
     assert L.pdwt_debug_set(b"nonsep_tiled", 0) == 0 and L.pdwt_debug_get(b"nonsep_tiled", C.byref(v)) == 0 and v.value == 0
     assert L.pdwt_debug_set(b"nonsep_tiled", 1) == 0
+
+
+def test_hot_kernels_keep_their_taps_in_scalar_registers():
+    """Static guard (no GPU): the kernels of the BASELINE configs and of the common wavelets must not park filter taps in VGPR lanes and
+    read them back per use (v_readlane: what slowed the first long-bank SWT inverse 2x and the 12-16-tap inverse levels by 5-11 %), nor
+    spill vector registers to scratch.  tools/isa_audit.py disassembles the code objects inside the built libpdwt_hip.so."""
+    import importlib.util
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump")
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows = {mod.demangle(n): (c, m) for n, c, m in mod.audit()}
+    assert len(rows) > 500
+    hot = {  # kernel (as c++filt prints it) -> largest tolerated share of v_readlane among its instructions
+        "k_fwd2d_casc<8, 2, 16, true>": 0.01, "k_inv2d_casc3<8, 16, true, true>": 0.01, "k_fwd2d_stream<8, 2>": 0.01,      # C2
+        "k_swt_fwd_fused<14, 0>": 0.01, "k_swt_inv_fused4<14, 1>": 0.01, "k_swt_inv_fused4<14, 2>": 0.01,                  # C3
+        "k_swt_inv_fusedp<14, 4>": 0.01, "k_swt_inv_fusedp<14, 8>": 0.01, "k_swt_inv_fusedp<14, 16>": 0.01,
+        "k_fwd1d_fused<float, 16, true>": 0.06, "k_inv1d_fused_pf<float, 16>": 0.06,  # C4 (read-lanes in the per-row set-up only, none in the item loops)
+        "k_fwd2d_f64lds<double, 40>": 0.06, "k_inv2d_f64lds<double, 40, 256>": 0.06,  # C5 (~25 per 300 FMAs: per-step bookkeeping scalars, not taps)
+        "k_inv2d_stream<8>": 0.01, "k_inv2d_stream<12>": 0.01, "k_inv2d_stream<16>": 0.01,                                  # db4 ... db8 / sym8 levels
+        "k_swt_inv_fused2<24, 1>": 0.03, "k_swt_inv_fused2<32, 1>": 0.06, "k_swt_inv_fused2<32, 2>": 0.06,                  # db11 ... db16 SWT
+    }
+    for k, lim in hot.items():
+        assert k in rows, "kernel %s is not in the library any more: update this list" % k
+        c, m = rows[k]
+        tot = sum(c.values())
+        share = c["v_readlane_b32"] / tot
+        assert share <= lim, (k, c["v_readlane_b32"], tot)
+        assert m.get("vgpr_spill_count", 0) == 0 and not any(op.startswith("scratch_") for op in c), (k, "scratch spills")
