@@ -841,6 +841,9 @@ int inv2d_casc3_f32(const float* A2, const float* H2, const float* V2, const flo
     switch (hlen) {
         case 4: return l3 ? launch_inv_casc3<4, true>(b, b3, out, trash, nr, nc, f, d_tbl, nimg) : launch_inv_casc3<4, false>(b, b3, out, trash, nr, nc, f, d_tbl, nimg);
         case 8: return l3 ? launch_inv_casc3<8, true>(b, b3, out, trash, nr, nc, f, d_tbl, nimg) : launch_inv_casc3<8, false>(b, b3, out, trash, nr, nc, f, d_tbl, nimg);
+        case 12: return l3 ? launch_inv_casc3<12, true>(b, b3, out, trash, nr, nc, f, d_tbl, nimg) : launch_inv_casc3<12, false>(b, b3, out, trash, nr, nc, f, d_tbl, nimg);
+        case 20: return l3 ? launch_inv_casc3<20, true>(b, b3, out, trash, nr, nc, f, d_tbl, nimg) : launch_inv_casc3<20, false>(b, b3, out, trash, nr, nc, f, d_tbl, nimg);
+        case 16: return l3 ? launch_inv_casc3<16, true>(b, b3, out, trash, nr, nc, f, d_tbl, nimg) : launch_inv_casc3<16, false>(b, b3, out, trash, nr, nc, f, d_tbl, nimg);
         default: return 1;
     }
 }
