@@ -889,7 +889,9 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
     constexpr int MAXVL = CascGeom<HLEN>::MAXVL;
     const int strips = idiv_up(nc, MAXVL * 4);
     const int VL = idiv_up(nc / 4, strips);
-    constexpr int NVD = (HLEN % 4 == 0 ? HLEN / 2 : HLEN);  // default prefetch distance
+    // default prefetch distance (row registers in flight); banks of more than 16 taps: 4 -- HLEN / 2 prologue rows plus a deeper prefetch
+    // would pass the 6-bit vmcnt counter
+    constexpr int NVD = HLEN > 16 ? 4 : (HLEN % 4 == 0 ? HLEN / 2 : HLEN);
     KTimer kt(K_FWD2D_CASC, true);
     // ---- workgroup form: W waves stacked in one strip hand their ring warm-up rows to the wave above through LDS, so only the
     // LAST wave of a workgroup re-reads and recomputes the 3(hlen-2) halo input rows (C2: 14 x 18 workgroups of 4 waves
@@ -985,7 +987,7 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
     else if (nv < HLEN && HLEN % 4 == 0)
         PDWT_LAUNCH_KT(kt, (k_fwd2d_casc<HLEN, NVD, 1>), grid, dim3(256), 0, in, b, nr, nc, VL, trash, cm, f);
     else
-        PDWT_LAUNCH_KT(kt, (k_fwd2d_casc<HLEN, HLEN, 1>), grid, dim3(256), 0, in, b, nr, nc, VL, trash, cm, f);
+        PDWT_LAUNCH_KT(kt, (k_fwd2d_casc<HLEN, (HLEN > 16 ? NVD : HLEN), 1>), grid, dim3(256), 0, in, b, nr, nc, VL, trash, cm, f);
     PDWT_CHECK_LAUNCH();
     return PDWT_OK;
 }
@@ -993,7 +995,7 @@ static int launch_fwd_casc(const float* in, const CascBands& b, float* trash, in
 #ifdef PDWT_CASC_ONLY8  // (quick ISA inspection builds)
 #define PDWT_CASC_FWD_HLENS(X) X(8)
 #else
-#define PDWT_CASC_FWD_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
+#define PDWT_CASC_FWD_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20)
 #endif
 
 int fwd2d_casc_f32(const float* in, float* H1, float* V1, float* D1, float* A2, float* H2, float* V2, float* D2, float* trash, int nr,

@@ -494,7 +494,7 @@ static int launch_inv_cascw(const CascInvBands& b, const CascInv3* b3, float* ou
     return PDWT_OK;
 }
 
-#define PDWT_CASCW_INV_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
+#define PDWT_CASCW_INV_HLENS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18)
 
 // A3 != NULL: three levels (A2 is not read: it is synthesised from the level-(l+2) bands on the fly)
 int inv2d_cascw_f32(const float* A2, const float* H2, const float* V2, const float* D2, const float* H1, const float* V1, const float* D1,

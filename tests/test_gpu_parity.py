@@ -421,7 +421,7 @@ def test_dropin_demo_program(tmp_path):
         assert abs(vals[0] - n_before) <= 2e-6 * n_before and abs(vals[1] - n_after) <= 2e-6 * n_after
 
 
-@pytest.mark.parametrize("wname", ["db2", "db3", "db4", "db5", "db6", "db7", "sym8", "db10"])
+@pytest.mark.parametrize("wname", ["db2", "db3", "db4", "db5", "db6", "db7", "sym8", "db9", "db10"])
 def test_cascade_equals_per_level(wname):
     """dwt_casc.hip (two levels per launch, approximation kept in registers) is the same arithmetic as one launch per level,
     and both match the oracle."""

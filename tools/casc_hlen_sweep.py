@@ -49,7 +49,7 @@ def run(wname, cfg):
 print("%d^2 L3, us per direction (kernel time)" % n)
 print("| wavelet (taps) | fwd: default | wg 16 | wg 8 | wg 4 | casc 0 | inv: default | iwg 16 | iwg 8 | iwg 4 | casc 0 |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")
-for wname in ("db2", "db3", "db4", "db5", "db6", "db7", "db8", "sym8", "coif2", "bior4.4", "db9", "db10"):
+for wname in ("db2", "db3", "db4", "db5", "db6", "db7", "db8", "sym8", "coif2", "bior4.4", "db9", "coif3", "db10"):
     fr, ir = [], []
     for cfg in ({}, {"casc_wg": 16, "casc_iwg": 16}, {"casc_wg": 8, "casc_iwg": 8}, {"casc_wg": 4, "casc_iwg": 4}, {"casc": 0}):
         hl, f, i = run(wname, cfg)
