@@ -185,7 +185,9 @@ def cpu_baseline(cfg, seconds_budget):
         "single_thread_value": round(res[1]["value"], 2),
         "all_cores_value": round(res[usable]["value"], 2) if usable in res else None, "usable_cores": usable,
         "host_cores": host, "affinity_cores": affinity, "cgroup_cpu_quota": quota,
-        "note": "usable_cores = min(affinity, cgroup cpu.max quota): what 'all cores' means for this process; teams beyond it share the quota",
+        "note": "`value` is the BEST OF the thread counts in by_threads, not an all-host-cores figure: usable_cores = min(affinity, cgroup cpu.max quota) "
+                "is what 'all cores' means for this process (the GPU boxes grant the container a quota of %s CPUs of a %d-thread host; teams beyond "
+                "the quota share it, and the host's other cores were never timed)" % ("%g" % quota if quota else "all", host),
         "by_threads": {str(k): round(v["value"], 1) for k, v in sorted(res.items())},
     }
 
@@ -430,20 +432,29 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
         L.pdwt_ktime_enable(1)
         L.pdwt_ktime_reset()
         ksteps = min(steps, 200)
+        ke0, ke1 = L.pdwt_event_create(), L.pdwt_event_create()
+        L.pdwt_event_record(ke0)
         for _ in range(ksteps):
             step()
+        L.pdwt_event_record(ke1)
         sync()
+        # One clock for the roofline fields.  The per-kernel pass carries two events per dispatch and may run at another clock than the
+        # timed pass (C4's kernel sum exceeded ms_per_step).  Its own duration is reported (`ktime_pass_ms_per_step`), and every
+        # figure derived from a kernel time (`roofline.achieved / frac`, `us_per_step_timed`) uses the kernel's SHARE of that pass applied
+        # to the timed step (`gpu_ms_per_step`): sum(us_per_step_timed) <= gpu_ms_per_step <= ms_per_step by construction.
+        ktime_pass_ms = L.pdwt_event_elapsed_ms(ke0, ke1) / ksteps
+        kscale = (gpu_ms / steps) / ktime_pass_ms if ktime_pass_ms > 0 else 1.0
         n, ms = C.c_int(), C.c_double()
         for k in range(L.pdwt_kernel_count()):
             L.pdwt_ktime_read(k, C.byref(n), C.byref(ms))
             if n.value:
                 kernels[L.pdwt_kernel_name(k).decode()] = dict(launches_per_step=n.value / ksteps, us_per_step=ms.value * 1e3 / ksteps,
-                                                               avg_us=ms.value * 1e3 / n.value)
+                                                               avg_us=ms.value * 1e3 / n.value, us_per_step_timed=ms.value * 1e3 / ksteps * kscale)
         L.pdwt_ktime_enable(0)
         L.pdwt_ktime_reset()
         dom, kb = pick_dominant(cfg, kernels, per_kernel_bytes, levels_eff)
         if dom:
-            ach = kb / (kernels[dom]["us_per_step"] * 1e-6) / 1e9
+            ach = kb / (kernels[dom]["us_per_step_timed"] * 1e-6) / 1e9
             # HBM bytes per launch: NOT measured in this run (PMC counters need rocprofv3 passes of their own).  The figure is
             # the one committed under profiles/ for this kernel -- (2*FETCH_SIZE + WRITE_SIZE) per the gfx950 correction of
             # MI355X_MICROARCH.md -- marked static with the commit it was taken at; null when the kernel has none.
@@ -463,7 +474,10 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
                         "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_static": traffic is not None,
                         "traffic_commit": tcommit, "traffic_stale": tstale, "traffic_source": tsrc,
                         "algorithmic_bytes_per_launch": kb / kernels[dom]["launches_per_step"],
-                        "avg_launch_us": round(kernels[dom]["avg_us"], 2), "launches_per_step": kernels[dom]["launches_per_step"],
+                        "avg_launch_us": round(kernels[dom]["avg_us"] * kscale, 2), "avg_launch_us_ktime_pass": round(kernels[dom]["avg_us"], 2),
+                        "launches_per_step": kernels[dom]["launches_per_step"],
+                        "ktime_pass_ms_per_step": round(ktime_pass_ms, 5), "ktime_scale": round(kscale, 4),
+                        "clock": "kernel times are shares of the per-kernel pass (events on every dispatch: ktime_pass_ms_per_step) applied to the timed step (gpu_ms_per_step)",
                         "step_compulsory_bytes": step_bytes,
                         "step_compulsory_GBps": round(step_bytes / (gpu_ms / steps * 1e-3) / 1e9, 1),
                         "step_frac_of_peak": round(step_bytes / (gpu_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
@@ -531,7 +545,7 @@ def run_config(name, args, L, torch, dist, rank, world, steps, warmup, settle_ms
                 fma += hl * 2 * r * c2
             c = c2
         # transform kernels only (measured kernel time, threshold and norm excluded) and the whole step
-        t_xf = sum(v["us_per_step"] for k, v in kernels.items() if k not in ("soft_thresh", "abs_sum", "abs_sum_final", "thresh_sum")) * 1e-6
+        t_xf = sum(v["us_per_step_timed"] for k, v in kernels.items() if k not in ("soft_thresh", "abs_sum", "abs_sum_final", "thresh_sum")) * 1e-6
         tf_step = 4.0 * fma / (gpu_ms / steps * 1e-3) / 1e12
         tf_xf = 4.0 * fma / t_xf / 1e12 if t_xf > 0 else None
         roofline["fp64"] = {"flop_per_step": 4 * fma, "achieved": round(tf_xf, 2) if tf_xf else None, "peak": FP64_VECTOR_PEAK_TFLOPS,
@@ -736,8 +750,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under torch.distributed.run, RCCL over
+            # xGMI for the barrier / max-over-ranks / norm all-reduce); rank 0 of the children prints the one JSON line
+            import socket
+            import subprocess
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            raise SystemExit(subprocess.call(cmd))
         args.gpus = world
 
     # torch first: its bundled ROCm runtime then also serves libpdwt_hip.so (one HIP runtime per process)

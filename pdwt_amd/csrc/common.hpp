@@ -155,7 +155,7 @@ enum KnobId {
     KN_F64_LDS_SKEW,       // dwt_lds.hip kernels, two workgroups per CU: % of a chunk pair's rows that go to the workgroup dispatched first (0 = even)
     KN_NORM2SQ_REF1D,      // 1: norm2sq of a 1-D transform adds sum|d| of the detail bands like the reference (src/wt.cu:389) instead of sum d^2
     KN_NORM_IN_THRESHOLD,  // sum|c| computed inside soft_threshold() and returned by the next norm1(): -1 = per instance (set_norm_cache), 0 = never, 1 = always
-    KN_SELFCHECK,          // 1: the first use of a hand-counted-wait kernel on a device runs pdwt_selfcheck_vmcnt_order() (cached; failure -> compiler-counted kernels); 0: trust the build guard
+    KN_SELFCHECK,          // 1: the first use of a hand-counted-wait kernel on a device runs pdwt_selfcheck_vmcnt_order() (cached; failure -> compiler-counted kernels); 0: trust the build guard; 2: behave as if it had failed (test hook)
     KN_DWT1D_F64,          // 0: per-level row kernels for batched 1-D in double precision instead of the fused all-levels kernels
     KN_SWTF_LONG,          // 0: two-pass SWT for banks of more than 20 taps instead of the run-time-tap-count fused level kernels
     KN_F64_TAIL,           // double-precision 2-D: levels of at most this many pixels per side run in ONE launch per direction (0 = off)

@@ -1115,7 +1115,11 @@ static Batch2D64* batch2d_create_f64(int nimg, double* const* d_images, double**
     for (int lev = 0; lev <= L; lev++) {
         B->lev_nr[lev] = nr;
         B->lev_nc[lev] = nc;
-        if (lev < L && (nr < 16 || nr < ((w.hlen + 7) / 8) * 8 || nc < ((w.hlen + 7) / 8) * 8)) {  // (what fwd2d_lds_any / inv2d_lds_any ask of a level)
+        // what fwd2d_lds_any asks of a level's input (nr, nc) AND what inv2d_lds_any asks of its coefficient size (div2(nr) rows >= the
+        // padded bank length -- the coarsest level included --, div2(nc) >= 2): a handle whose forward runs but whose inverse is refused
+        // would break the "NULL otherwise" contract of the header
+        const int hp = ((w.hlen + 7) / 8) * 8;
+        if (lev < L && (nr < 16 || nr < hp || nc < hp || div2(nr) < hp || div2(nc) < 2)) {
             delete B;
             return nullptr;
         }
@@ -1198,6 +1202,17 @@ static int batch2d_inverse_f64(Batch2D64* B, const pdwt_filters_f64* filt)
 
 }  // namespace pdwt
 
+// hlen == 2 MEANS Haar in this entry (as in the class, which sends every 2-tap transform to pdwt_haar_*, src/wt.cu:236-271): the Haar
+// kernels take no bank, so a 2-tap bank that is not Haar's must not come back as PDWT_OK with Haar coefficients
+template <typename F>
+static bool bank_is_haar(const F* f)
+{
+    if (!f || f->hlen != 2) return false;
+    const double r = 0.70710678118654752440, tol = 1e-6;
+    auto near = [&](double a, double b) { return a - b <= tol && b - a <= tol; };
+    return near(f->L[0], r) && near(f->L[1], r) && near(f->H[0], -r) && near(f->H[1], r) && near(f->IL[0], r) && near(f->IL[1], r) && near(f->IH[0], r) && near(f->IH[1], -r);
+}
+
 using namespace pdwt;
 
 extern "C" {
@@ -1223,6 +1238,7 @@ int pdwt_batch2d_forward_f64(void* batch, const pdwt_filters_f64* f)
 {
     const int k = batch_kind(batch, 8);
     if (k == 2) {
+        if (!bank_is_haar(f)) return PDWT_EINVAL;
         Batch2DDev on_dev(((BatchHaar*)batch)->dev);
         return haar_batch_forward<double>(((BatchHaar*)batch)->hb);
     }
@@ -1232,6 +1248,7 @@ int pdwt_batch2d_inverse_f64(void* batch, const pdwt_filters_f64* f)
 {
     const int k = batch_kind(batch, 8);
     if (k == 2) {
+        if (!bank_is_haar(f)) return PDWT_EINVAL;
         Batch2DDev on_dev(((BatchHaar*)batch)->dev);
         return haar_batch_inverse<double>(((BatchHaar*)batch)->hb);
     }
@@ -1247,6 +1264,7 @@ int pdwt_batch2d_forward_f32(void* batch, const pdwt_filters_f32* f)
 {
     const int k = batch_kind(batch, 4);
     if (k == 2 || k == 3) {
+        if (k == 2 && !bank_is_haar(f)) return PDWT_EINVAL;
         Batch2DDev on_dev(((BatchHaar*)batch)->dev);
         return k == 2 ? haar_batch_forward<float>(((BatchHaar*)batch)->hb) : swt_batch_forward_f32(((BatchHaar*)batch)->hb, f);
     }
@@ -1256,6 +1274,7 @@ int pdwt_batch2d_inverse_f32(void* batch, const pdwt_filters_f32* f)
 {
     const int k = batch_kind(batch, 4);
     if (k == 2 || k == 3) {
+        if (k == 2 && !bank_is_haar(f)) return PDWT_EINVAL;
         Batch2DDev on_dev(((BatchHaar*)batch)->dev);
         return k == 2 ? haar_batch_inverse<float>(((BatchHaar*)batch)->hb) : swt_batch_inverse_f32(((BatchHaar*)batch)->hb, f);
     }

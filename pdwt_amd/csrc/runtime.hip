@@ -337,6 +337,9 @@ int pdwt_event_destroy(void* ev)
 int pdwt_graph_allowed(void) { return (g_kt_on || g_probe_on) ? 0 : 1; }  // per-kernel event timing / the clock probe (allocates on first use) and capture do not mix
 int pdwt_graph_capture_begin(void)
 {
+    // the self-check of the hand-counted waits cannot run inside a capture (allocations, a host read-back): take the device's verdict NOW,
+    // so that the kernels recorded into the graph are the ones the check allows (a graph user's first transform is the captured one)
+    (void)pdwt::counted_waits_ok();
     PDWT_HIP_TRY(hipStreamBeginCapture(pdwt::stream(), hipStreamCaptureModeThreadLocal));
     return PDWT_OK;
 }

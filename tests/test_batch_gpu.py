@@ -185,6 +185,51 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     assert len(d["per_rank"]["sclk_mhz_mean"]) == 2 and len(d["per_rank"]["socket_w_mean"]) == 2
 
 
+@pytest.mark.timeout(600)
+def test_bench_plain_form_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher (WORLD_SIZE unset): bench.py re-executes itself under torch.distributed.run, one process
+    per rank (the plain form used to exit with "must be launched with torch.distributed.run", which would have cost
+    the first 8-GPU scaling run its curve).  One JSON line, the communicator holds 2 ranks."""
+    import json
+    import subprocess
+    env = dict(os.environ, PDWT_BENCH_ONE_GPU="1", PDWT_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0",
+                        "--settle-ms", "20", "--no-others"], capture_output=True, text=True, timeout=580, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["collective"] == {"backend": "gloo", "ranks": 2}
+    assert d["sanity"]["norm1_ranks"] == 2 and d["roundtrip_max_rel_err"] <= 1e-5
+
+
+@pytest.mark.timeout(900)
+def test_bench_line_kernel_times_fit_the_timed_step():
+    """One clock for the roofline fields: in every config of the default line the per-kernel times that the roofline
+    figures are derived from (`us_per_step_timed`: a kernel's share of the per-kernel pass applied to the timed step) add up to no more than
+    `ms_per_step`, the per-kernel pass states its own duration, and `roofline.achieved` follows from the dominant kernel's timed share."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--cpu-seconds", "0", "--settle-ms", "50"],
+                       capture_output=True, text=True, timeout=880, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cfgs = {"c2": d}
+    cfgs.update(d["other_configs"])
+    for name, c in cfgs.items():
+        assert "error" not in c, (name, c)
+        tot = sum(k["us_per_step_timed"] for k in c["kernels"].values())
+        assert tot <= c["gpu_ms_per_step"] * 1e3 * 1.0005 + 0.01, (name, tot, c["gpu_ms_per_step"])
+        assert c["gpu_ms_per_step"] <= c["ms_per_step"] * 1.15, (name, c["gpu_ms_per_step"], c["ms_per_step"])
+        rf = c["roofline"]
+        assert rf["ktime_pass_ms_per_step"] > 0 and rf["ktime_scale"] > 0
+        dom = c["kernels"][rf["kernel"]]
+        ach = rf["algorithmic_bytes_per_launch"] * dom["launches_per_step"] / (dom["us_per_step_timed"] * 1e-6) / 1e9
+        assert abs(ach - rf["achieved"]) <= 0.01 * rf["achieved"] + 0.2, (name, ach, rf["achieved"])
+
+
 @pytest.mark.parametrize("exe,shards", [("batch_demo", 3), ("batch_demod", 2), ("batch_demo", 8), ("batch_demo", 1), ("batch_demod", 1)])
 def test_one_process_batch_split_cpp(exe, shards):
     """include/wt_batch.h: the batch split driven from ONE host process through the C++ class (an instance per shard on

@@ -319,6 +319,52 @@ def test_config3_swt_db7_L5_full_size_vs_oracle():
         orc.set_num_threads(min(16, os.cpu_count() or 1))
 
 
+def test_selfcheck_failed_fallback_runs_c2_and_c3_full_size():
+    """VERDICT r5 item 7.  The hand-counted-wait kernels (streaming, cascade, fused SWT levels) are gated by the device self-check
+    (selfcheck.hip: counted_waits_ok()).  With the knob set to "failed" (selfcheck = 2) every such dispatcher must decline and the
+    compiler-counted kernels (LDS-tiled / two-pass) must carry BASELINE configs[1] and configs[2] at full size -- the path a future
+    gfx950 stepping or ROCm release would silently take.  C2: every band bit for bit against the oracle; C3: every band within the
+    parity tolerance; round trips.  No wave-program / cascade launch may be counted while the knob is set."""
+    from tests.helpers import knobs
+    L = pdwt_amd.hip()
+    rs = np.random.RandomState(11)
+    x = rs.uniform(0, 255, (4096, 4096)).astype(np.float32)
+    orc.set_num_threads(orc.usable_cores())
+    try:
+        with knobs(selfcheck=2):
+            L.pdwt_ktime_enable(1)
+            L.pdwt_ktime_reset()
+            W, O = _check_against_oracle(x, "db4", 3, exact=True)
+            assert band_err(W.get_image(), x) <= 1e-5
+            W3, O3 = _pair(x, "db7", 5, do_swt=1)
+            W3.forward()
+            O3.forward()
+            for k in range(W3.nbands):
+                e = band_err(W3.get_coeff(k), O3.get_coeff(k))
+                assert e <= 1e-5, ("swt band", k, e)
+            W3.inverse()
+            O3.inverse()
+            gi = W3.get_image()
+            assert band_err(gi, O3.get_image()) <= 1e-5 and band_err(gi, x) <= 1e-5
+            # which kernels ran: none of the hand-counted families
+            import ctypes as C
+            n, ms = C.c_int(), C.c_double()
+            ran = set()
+            for k in range(L.pdwt_kernel_count()):
+                L.pdwt_ktime_read(k, C.byref(n), C.byref(ms))
+                if n.value:
+                    ran.add(L.pdwt_kernel_name(k).decode())
+            L.pdwt_ktime_enable(0)
+            L.pdwt_ktime_reset()
+            counted = {k for k in ran if "casc" in k or "stream" in k}
+            assert not counted, (counted, ran)
+            # (the fused SWT levels are timed under the column kernels' names; the two-pass form is the one that also launches row kernels)
+            assert "swt_ana_rows" in ran and "swt_syn_rows" in ran, ran
+    finally:
+        L.pdwt_ktime_enable(0)
+        orc.set_num_threads(min(16, os.cpu_count() or 1))
+
+
 def test_config4_batched_1d_shard_sym8_L4():
     """configs[3], one GPU's shard of the 8-way split: 8192 x 8192 float32 sym8 4 levels."""
     rs = np.random.RandomState(1)
@@ -1523,8 +1569,8 @@ def test_batch2d_handles_are_bound_to_their_precision():
     EINVAL = -1
     made = []
 
-    def make(sfx, ct, hlen, n=256):
-        info = nat.Info(2, n, n, 1, 0, hlen)
+    def make(sfx, ct, hlen, n=256, levels=1):
+        info = nat.Info(2, n, n, levels, 0, hlen)
         imgs, tmps, cfs = [], [], []
         for _ in range(2):
             imgs.append(L.pdwt_malloc(n * n * C.sizeof(ct)))
@@ -1543,21 +1589,52 @@ def test_batch2d_handles_are_bound_to_their_precision():
     for sfx in ("f32", "f64"):
         filt[sfx] = FT[sfx]()
         assert getattr(L, "pdwt_compute_filters_separable_" + sfx)(b"db4", 0, C.byref(filt[sfx])) == 8
+    haar = {}
+    for sfx in ("f32", "f64"):
+        haar[sfx] = FT[sfx]()
+        assert getattr(L, "pdwt_compute_filters_separable_" + sfx)(b"haar", 0, C.byref(haar[sfx])) == 2
     try:
         for hlen in (2, 8):
             h32 = make("f32", C.c_float, hlen)
             h64 = make("f64", C.c_double, hlen)
             assert h32 and h64
-            assert L.pdwt_batch2d_forward_f64(h32, C.byref(filt["f64"])) == EINVAL
-            assert L.pdwt_batch2d_inverse_f64(h32, C.byref(filt["f64"])) == EINVAL
-            assert L.pdwt_batch2d_forward_f32(h64, C.byref(filt["f32"])) == EINVAL
-            assert L.pdwt_batch2d_inverse_f32(h64, C.byref(filt["f32"])) == EINVAL
-            assert L.pdwt_batch2d_forward_f32(h32, C.byref(filt["f32"])) == 0
-            assert L.pdwt_batch2d_forward_f64(h64, C.byref(filt["f64"])) == 0
+            bank = haar if hlen == 2 else filt
+            assert L.pdwt_batch2d_forward_f64(h32, C.byref(bank["f64"])) == EINVAL
+            assert L.pdwt_batch2d_inverse_f64(h32, C.byref(bank["f64"])) == EINVAL
+            assert L.pdwt_batch2d_forward_f32(h64, C.byref(bank["f32"])) == EINVAL
+            assert L.pdwt_batch2d_inverse_f32(h64, C.byref(bank["f32"])) == EINVAL
+            if hlen == 2:
+                # hlen == 2 means Haar in this entry; the Haar kernels take no bank, so a missing bank, a bank of another length or a
+                # 2-tap bank that is not Haar's is refused instead of coming back PDWT_OK with Haar coefficients
+                odd2 = FT["f32"]()
+                odd2.hlen = 2
+                for name, vals in (("L", (0.6, 0.8)), ("H", (-0.8, 0.6)), ("IL", (0.8, 0.6)), ("IH", (0.6, -0.8))):
+                    for i, v in enumerate(vals):
+                        getattr(odd2, name)[i] = v
+                for bad in (None, C.byref(filt["f32"]), C.byref(odd2)):
+                    assert L.pdwt_batch2d_forward_f32(h32, bad) == EINVAL
+                    assert L.pdwt_batch2d_inverse_f32(h32, bad) == EINVAL
+                assert L.pdwt_batch2d_forward_f64(h64, None) == EINVAL and L.pdwt_batch2d_inverse_f64(h64, C.byref(filt["f64"])) == EINVAL
+            assert L.pdwt_batch2d_forward_f32(h32, C.byref(bank["f32"])) == 0
+            assert L.pdwt_batch2d_forward_f64(h64, C.byref(bank["f64"])) == 0
+            assert L.pdwt_batch2d_inverse_f32(h32, C.byref(bank["f32"])) == 0
+            assert L.pdwt_batch2d_inverse_f64(h64, C.byref(bank["f64"])) == 0
             L.pdwt_sync()
             L.pdwt_batch2d_destroy_f64(h32)  # (either destroy, any handle)
             L.pdwt_batch2d_destroy(h64)
         assert L.pdwt_batch2d_forward_f32(None, C.byref(filt["f32"])) == EINVAL
+        # create must apply the INVERSE level kernel's predicate too -- coefficient rows of every level, the coarsest
+        # included, >= the padded bank length -- or the handle's forward runs and every inverse is refused.  db8 (16 taps) in double:
+        # 64^2 L3 ends at 8 rows, 512^2 L6 as well: NULL ("run the images one by one"); 512^2 L5 ends at 16 rows: a handle whose inverse runs
+        f16 = FT["f64"]()
+        assert L.pdwt_compute_filters_separable_f64(b"db8", 0, C.byref(f16)) == 16
+        assert not make("f64", C.c_double, 16, n=64, levels=3)
+        assert not make("f64", C.c_double, 16, n=512, levels=6)
+        h = make("f64", C.c_double, 16, n=512, levels=5)
+        assert h
+        assert L.pdwt_batch2d_forward_f64(h, C.byref(f16)) == 0 and L.pdwt_batch2d_inverse_f64(h, C.byref(f16)) == 0
+        L.pdwt_sync()
+        L.pdwt_batch2d_destroy(h)
     finally:
         L.pdwt_sync()
         for sfx, info, imgs, tmps, cfs in made:
