@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "dwt_lds.hpp"
+#include "dwt_lat.hpp"
 #include "dwt_stream.hpp"
 #include "dwt_casc.hpp"
 #include "casc_dev.hpp"
@@ -564,7 +565,9 @@ static int level_fwd2d(const T* in, T* cA, T* cH, T* cV, T* cD, T* t1, T* t2, si
 {
     if constexpr (sizeof(T) == 8) {  // double-precision banks: row + column pass in one launch (dwt_lds.hip)
         if (!force_twopass()) {
-            const int rc = fwd2d_f64_lds(in, cA, cH, cV, cD, taps_dev, nr, nc, hlen, f);
+            int rc = fwd2d_f64_lat(in, cA, cH, cV, cD, nr, nc, hlen, f);  // orthogonal banks with a lattice table, large even levels (dwt_lat.hip)
+            if (rc <= 0) return rc;
+            rc = fwd2d_f64_lds(in, cA, cH, cV, cD, taps_dev, nr, nc, hlen, f);
             if (rc <= 0) return rc;
         }
     }
@@ -605,7 +608,9 @@ static int level_inv2d(const T* cA, const T* cH, const T* cV, const T* cD, T* ou
 {
     if constexpr (sizeof(T) == 8) {  // double-precision banks: column + row synthesis in one launch (dwt_lds.hip)
         if (!force_twopass()) {
-            const int rc = inv2d_f64_lds(cA, cH, cV, cD, out, taps_dev, nri, nci, nro, nco, hlen, f);
+            int rc = inv2d_f64_lat(cA, cH, cV, cD, out, nri, nci, nro, nco, hlen, f);
+            if (rc <= 0) return rc;
+            rc = inv2d_f64_lds(cA, cH, cV, cD, out, taps_dev, nri, nci, nro, nco, hlen, f);
             if (rc <= 0) return rc;
         }
     }

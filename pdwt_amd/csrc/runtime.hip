@@ -77,6 +77,7 @@ static const KnobDef g_knob_defs[KN_COUNT] = {
     {"norm_in_threshold", "PDWT_NORM_IN_THRESHOLD", -1},
     {"selfcheck", "PDWT_SELFCHECK", 1}, {"dwt1d_f64", "PDWT_DWT1D_F64", 1}, {"swtf_long", "PDWT_SWTF_LONG", 1}, {"f64_tail", "PDWT_F64_TAIL", 0},
     {"exp0", "PDWT_EXP0", 0}, {"exp1", "PDWT_EXP1", 0}, {"exp2", "PDWT_EXP2", 0}, {"exp3", "PDWT_EXP3", 0}, {"nonsep_tiled", "PDWT_NONSEP_TILED", 1},
+    {"f64_lat", "PDWT_F64_LAT", 1}, {"f64_lat_min", "PDWT_F64_LAT_MIN", 4096},
 };
 static int g_knob_vals[KN_COUNT];
 static std::once_flag g_knob_once;
@@ -109,6 +110,9 @@ int knob_set(const char* name, int value)
 // kernels since the process started)
 std::atomic<int> g_stat_spec_fwd{0}, g_stat_spec_inv{0};
 void stat_casc_spec(int inverse) { (inverse ? g_stat_spec_inv : g_stat_spec_fwd).fetch_add(1, std::memory_order_relaxed); }
+// ("stat_lat_fwd" / "stat_lat_inv": launches of the lattice level kernels of dwt_lat.hip)
+std::atomic<int> g_stat_lat_fwd{0}, g_stat_lat_inv{0};
+void stat_lat(int inverse) { (inverse ? g_stat_lat_inv : g_stat_lat_fwd).fetch_add(1, std::memory_order_relaxed); }
 
 int knob_get(const char* name, int* value)
 {
@@ -116,6 +120,10 @@ int knob_get(const char* name, int* value)
     if (!name || !value) return PDWT_EINVAL;
     if (!strcmp(name, "stat_casc_spec_fwd") || !strcmp(name, "stat_casc_spec_inv")) {
         *value = (name[15] == 'f' ? g_stat_spec_fwd : g_stat_spec_inv).load(std::memory_order_relaxed);
+        return PDWT_OK;
+    }
+    if (!strcmp(name, "stat_lat_fwd") || !strcmp(name, "stat_lat_inv")) {
+        *value = (name[9] == 'f' ? g_stat_lat_fwd : g_stat_lat_inv).load(std::memory_order_relaxed);
         return PDWT_OK;
     }
     for (int i = 0; i < KN_COUNT; i++) {

@@ -365,6 +365,86 @@ def test_selfcheck_failed_fallback_runs_c2_and_c3_full_size():
         orc.set_num_threads(min(16, os.cpu_count() or 1))
 
 
+def _lat_stat(name):
+    import ctypes as C
+    v = C.c_int()
+    assert pdwt_amd.hip().pdwt_debug_get(name, C.byref(v)) == 0
+    return v.value
+
+
+@pytest.mark.parametrize("case", [((1024, 1024), 1), ((2048, 1024), 1), ((1024, 2048), 2), ((1288, 1536), 1), ((4096, 4096), 3)])
+def test_lattice_levels_vs_oracle(case):
+    """dwt_lat.hip: level kernels of the orthogonal double-precision banks whose COLUMN pass runs as a paraunitary lattice (round 6, BASELINE
+    config 5).  Not the reference's summation order, so not bit-identical to the oracle -- every band within 1e-12 of the coefficients' scale
+    (measured ~1e-15; the double-precision parity tolerance is 1e-10), against the oracle AND against the direct-form level kernels of the
+    library itself (knob f64_lat = 0, which ARE bit-identical to the oracle); the inverse alone on the oracle's coefficients; the round trip.
+    Shapes: chunk counts that split evenly and not (1288 rows: chunks of unequal height), two workgroups per CU with the weighted row split
+    (4096^2) and without; levels forced into the path with f64_lat_min (the default takes levels of 4096 and more).  The launch counters
+    prove the lattice kernels ran."""
+    from tests.helpers import knobs
+    shape, lev = case
+    rs = np.random.RandomState(shape[0] + 7 * lev)
+    x = rs.uniform(-100, 100, shape)
+    orc.set_num_threads(orc.usable_cores())
+    try:
+        O = orc.OracleWavelets(x, "db20", lev)
+        O.forward()
+        res = {}
+        for lat in (1, 0):
+            with knobs(f64_lat=lat, f64_lat_min=512):
+                f0, i0 = _lat_stat(b"stat_lat_fwd"), _lat_stat(b"stat_lat_inv")
+                W = pdwt_amd.Wavelets(x, "db20", lev, dtype="float64")
+                W.forward()
+                c = W.coeffs
+                W.inverse()
+                rt = W.get_image()
+                W2 = pdwt_amd.Wavelets(x, "db20", lev, dtype="float64")
+                W2.forward()
+                for k in range(W2.nbands):
+                    W2.set_coeff(O.get_coeff(k), k)
+                W2.inverse()
+                res[lat] = (c, rt, W2.get_image())
+                ran_f, ran_i = _lat_stat(b"stat_lat_fwd") - f0, _lat_stat(b"stat_lat_inv") - i0
+                assert (ran_f > 0 and ran_i > 0) if lat else (ran_f == 0 and ran_i == 0), (lat, ran_f, ran_i)
+        for k in range(len(res[1][0])):
+            o = O.get_coeff(k)
+            assert np.array_equal(res[0][0][k], o), ("direct form", k)  # the direct-form kernels: the oracle's arithmetic
+            assert band_err(res[1][0][k], o) <= 1e-12, ("lattice vs oracle", k, band_err(res[1][0][k], o))
+        for lat in (1, 0):
+            assert band_err(res[lat][1], x) <= 1e-12, ("round trip", lat)
+            assert band_err(res[lat][2], x) <= 1e-12, ("inverse of the oracle's bands", lat)
+        assert band_err(res[1][1], res[0][1]) <= 1e-12
+    finally:
+        orc.set_num_threads(min(16, os.cpu_count() or 1))
+
+
+def test_lattice_path_is_taken_by_named_orthogonal_banks_only():
+    """The lattice table is keyed by EXACT tap equality with a named bank (tools/gen_lattice.py emits db2..db20, sym9, coif1..5; kernels are
+    instantiated for 40 taps): a custom bank -- db20's own taps scaled by 1 + 2^-40 -- and every other bank keep the direct-form kernels."""
+    from tests.helpers import knobs
+    rs = np.random.RandomState(5)
+    x = rs.uniform(-10, 10, (1024, 1024))
+    with knobs(f64_lat_min=512):
+        for wname, expect in (("db20", True), ("sym20", False), ("db16", False), ("bior6.8", False)):
+            f0 = _lat_stat(b"stat_lat_fwd")
+            W = pdwt_amd.Wavelets(x, wname, 1, dtype="float64")
+            W.forward()
+            W.inverse()
+            assert (_lat_stat(b"stat_lat_fwd") > f0) == expect, wname
+            assert band_err(W.get_image(), x) <= 1e-10
+        # custom bank: the class's set_filters_* with perturbed taps
+        hlen, fb, _ = orc.filters("db20", np.float64)
+        sc = 1.0 + 2.0 ** -40
+        W = pdwt_amd.Wavelets(x, "db20", 1, dtype="float64")
+        assert W.set_filters_forward("custom", fb["L"] * sc, fb["H"] * sc) == 0
+        assert W.set_filters_inverse(fb["IL"] / sc, fb["IH"] / sc) == 0
+        f0, i0 = _lat_stat(b"stat_lat_fwd"), _lat_stat(b"stat_lat_inv")
+        W.forward()
+        W.inverse()
+        assert _lat_stat(b"stat_lat_fwd") == f0 and _lat_stat(b"stat_lat_inv") == i0
+        assert band_err(W.get_image(), x) <= 1e-10
+
+
 def test_config4_batched_1d_shard_sym8_L4():
     """configs[3], one GPU's shard of the 8-way split: 8192 x 8192 float32 sym8 4 levels."""
     rs = np.random.RandomState(1)

@@ -21,7 +21,7 @@ a = ap.parse_args()
 import torch
 L = pdwt_amd.hip()
 x = torch.randn(a.size, a.size, device="cuda", dtype=torch.float64 if a.dtype == "float64" else torch.float32)
-W = pdwt_amd.Wavelets(x, a.wname, 1)
+W = pdwt_amd.Wavelets(None, a.wname, 1, dtype=a.dtype, shape=(a.size, a.size), device_ptr=x.data_ptr())
 for _ in range(10):
     W.forward()
     W.inverse()
