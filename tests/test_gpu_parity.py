@@ -995,7 +995,9 @@ def test_f64_long_filter_level_kernels_random_shapes():
         x = rs.uniform(-10, 10, (nr, nc))
         res = []
         for kn in (dict(), dict(force_twopass=1), dict(f64_lds=0)):
-            with knobs(f64_lds_min=0, **kn):
+            # (f64_lat = 0: this test is about the DIRECT-form kernels, which share the oracle's arithmetic bit for bit; the lattice level
+            #  kernels of round 6 -- db20 levels of 4096^2 and more by default -- agree to ~1e-15 and have test_lattice_levels_vs_oracle)
+            with knobs(f64_lds_min=0, f64_lat=0, **kn):
                 W = pdwt_amd.Wavelets(x, "db20", lev)
                 W.forward()
                 c = W.coeffs
