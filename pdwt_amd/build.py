@@ -20,7 +20,7 @@ LIB = os.path.join(PKG, "lib")
 INC = os.path.join(ROOT, "include")
 
 # (the slowest translation units first: the pool starts jobs in this order, and the build's wall time is the longest chain)
-HIP_SOURCES = ["dwt_lat.hip", "swt_fused_l2_fwd.hip", "swt_fused_l2_inv.hip", "swt_fused_l2_inv1.hip", "swt_fused_l2_inv2.hip", "swt_fused_l2_inv4.hip", "dwt_lds.hip", "dwt_casc_inv3.hip", "dwt_casc.hip", "dwt_casc_invw.hip", "swt_fused_inv.hip", "swt_fused_invp.hip", "swt_fused_fwd.hip", "swt_fused_fwd_long.hip", "swt_fused_inv_long.hip", "swt_fused_f64_fwd.hip", "swt_fused_f64_inv.hip", "dwt1d_fused.hip", "dwt_stream.hip", "cols_ring_dwt_f32.hip", "cols_ring_dwt_f64.hip", "cols_ring_swt_f32.hip", "cols_ring_swt_f64.hip", "rows_tr.hip", "runtime.hip", "coeffs.hip", "dwt.hip", "swt.hip", "haar.hip", "utils.hip", "nonsep.hip", "collective.hip", "selfcheck.hip", "filters.cpp"]
+HIP_SOURCES = ["dwt_lat.hip", "swt_fused_l2_fwd.hip", "swt_fused_l2_inv.hip", "swt_fused_l2_inv1.hip", "swt_fused_l2_inv2.hip", "swt_fused_l2_inv4.hip", "dwt_lds.hip", "dwt_casc_inv3.hip", "dwt_casc.hip", "dwt_casc_invw.hip", "swt_fused_inv.hip", "swt_fused_invp.hip", "swt_fused_fwd.hip", "swt_fused_fwd_long.hip", "swt_fused_inv_long.hip", "swt_fused_f64_fwd.hip", "swt_fused_f64_inv.hip", "dwt1d_fused.hip", "dwt1d_fused_nt.hip", "dwt_stream.hip", "cols_ring_dwt_f32.hip", "cols_ring_dwt_f64.hip", "cols_ring_swt_f32.hip", "cols_ring_swt_f64.hip", "rows_tr.hip", "runtime.hip", "coeffs.hip", "dwt.hip", "swt.hip", "haar.hip", "utils.hip", "nonsep.hip", "collective.hip", "selfcheck.hip", "filters.cpp"]
 HOST_SOURCES = ["wt.cpp", "wt_capi.cpp"]
 # (kept for reference; an object's real dependencies are the files its source includes, transitively: _deps())
 HIP_DEPS = ["common.hpp", "dwt_stream.hpp", "stream_dev.hpp", "dwt_casc.hpp", "casc_dev.hpp", "dwt_lds.hpp", "swt_fused.hpp", "swt_fused.inc", "swt_fused_l2.inc", "swt_fused_f64.inc", "dwt1d_fused.hpp", "cols_ring.hpp", "cols_ring.inc", "rows_tr.hpp", "tapreg.hpp", "filters_table.inc"]

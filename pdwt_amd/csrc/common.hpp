@@ -166,6 +166,7 @@ enum KnobId {
     KN_NONSEP_TILED,       // custom non-separable banks (nonsep.hip): 1 = LDS-tiled kernels for levels that fill the chip, 0 = one-thread-per-output kernels, 2 = tiled at every size
     KN_F64_LAT,            // 0: direct-form level kernels (dwt_lds.hip) also for the orthogonal double-precision banks that have a lattice table (dwt_lat.hip)
     KN_F64_LAT_MIN,        // ... smallest level side (pixels) the lattice level kernels take
+    KN_DWT1D_NT_MB,        // batched 1-D, float32: smallest image (MB) whose fused kernels read their rows / bands with non-temporal loads (0 = never)
     KN_COUNT
 };
 int knob(KnobId id);

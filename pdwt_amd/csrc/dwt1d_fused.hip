@@ -22,7 +22,16 @@
 #include "common.hpp"
 #include "dwt1d_fused.hpp"
 
+// This file is compiled TWICE: as itself (variant `dflt`: default cache policy) and through dwt1d_fused_nt.hip (variant `nt`: float32 only,
+// PDWT_1D_NT = 5 -- non-temporal row loads in the forward and band loads in the inverse kernels).  forward_separable_1d / inverse_separable_1d
+// (dwt.hip) take the `nt` variant for batches that do not fit the Infinity Cache (knob dwt1d_nt_mb): a row that is read once then leaves no line
+// behind -- C4 (8192 x 8192 float32, 268 MB per image): -2.5 % over 20 interleaved pairs; a 64 MB batch that LIVES in the cache would lose 3-18 %.
+#ifndef PDWT_1D_VARIANT
+#define PDWT_1D_VARIANT dflt
+#endif
+
 namespace pdwt {
+namespace PDWT_1D_VARIANT {
 
 constexpr int kMaxLev1D = 32;
 
@@ -898,8 +907,11 @@ int inv1d_fused(T* out, T** c, const pdwt_info& w, const Taps2<T>& f)
 }
 
 template int fwd1d_fused<float>(const float*, float**, const pdwt_info&, const Taps2<float>&);
-template int fwd1d_fused<double>(const double*, double**, const pdwt_info&, const Taps2<double>&);
 template int inv1d_fused<float>(float*, float**, const pdwt_info&, const Taps2<float>&);
+#ifndef PDWT_1D_FLOAT_ONLY
+template int fwd1d_fused<double>(const double*, double**, const pdwt_info&, const Taps2<double>&);
 template int inv1d_fused<double>(double*, double**, const pdwt_info&, const Taps2<double>&);
+#endif
 
+}  // namespace PDWT_1D_VARIANT
 }  // namespace pdwt

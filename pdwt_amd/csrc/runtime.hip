@@ -77,7 +77,7 @@ static const KnobDef g_knob_defs[KN_COUNT] = {
     {"norm_in_threshold", "PDWT_NORM_IN_THRESHOLD", -1},
     {"selfcheck", "PDWT_SELFCHECK", 1}, {"dwt1d_f64", "PDWT_DWT1D_F64", 1}, {"swtf_long", "PDWT_SWTF_LONG", 1}, {"f64_tail", "PDWT_F64_TAIL", 0},
     {"exp0", "PDWT_EXP0", 0}, {"exp1", "PDWT_EXP1", 0}, {"exp2", "PDWT_EXP2", 0}, {"exp3", "PDWT_EXP3", 0}, {"nonsep_tiled", "PDWT_NONSEP_TILED", 1},
-    {"f64_lat", "PDWT_F64_LAT", 1}, {"f64_lat_min", "PDWT_F64_LAT_MIN", 4096},
+    {"f64_lat", "PDWT_F64_LAT", 1}, {"f64_lat_min", "PDWT_F64_LAT_MIN", 4096}, {"dwt1d_nt_mb", "PDWT_DWT1D_NT_MB", 192},
 };
 static int g_knob_vals[KN_COUNT];
 static std::once_flag g_knob_once;

@@ -167,8 +167,10 @@ def test_hot_kernels_keep_their_taps_in_scalar_registers():
         "k_fwd2d_casc<8, 2, 16, true>": 0.01, "k_inv2d_casc3<8, 16, true, true>": 0.01, "k_fwd2d_stream<8, 2>": 0.01,      # C2
         "k_swt_fwd_fused<14, 0>": 0.01, "k_swt_inv_fused4<14, 1>": 0.01, "k_swt_inv_fused4<14, 2>": 0.01,                  # C3
         "k_swt_inv_fusedp<14, 4>": 0.01, "k_swt_inv_fusedp<14, 8>": 0.01, "k_swt_inv_fusedp<14, 16>": 0.01,
-        "k_fwd1d_fused<float, 16, true>": 0.06, "k_inv1d_fused_pf<float, 16>": 0.06,  # C4 (read-lanes in the per-row set-up only, none in the item loops)
-        "k_fwd2d_f64lds<double, 40>": 0.06, "k_inv2d_f64lds<double, 40, 256>": 0.06,  # C5 (~25 per 300 FMAs: per-step bookkeeping scalars, not taps)
+        "dflt::k_fwd1d_fused<float, 16, true>": 0.06, "dflt::k_inv1d_fused_pf<float, 16>": 0.06,  # C4 (read-lanes in the per-row set-up only, none in the item loops)
+        "nt::k_fwd1d_fused<float, 16, true>": 0.06, "nt::k_inv1d_fused_pf<float, 16>": 0.06,      # ... the same file compiled with non-temporal loads (round 6)
+        "k_fwd2d_lat<40>": 0.0, "k_inv2d_lat<40>": 0.0,                                # C5 levels 1-2 (round 6: lattice level kernels; no scalar spill at all)
+        "k_fwd2d_f64lds<double, 40>": 0.06, "k_inv2d_f64lds<double, 40, 256>": 0.06,  # C5 levels 3-6 (~25 per 300 FMAs: per-step bookkeeping scalars, not taps)
         "k_inv2d_stream<8>": 0.01, "k_inv2d_stream<12>": 0.01, "k_inv2d_stream<16>": 0.01,                                  # db4 ... db8 / sym8 levels
         "k_swt_inv_fused2<24, 1>": 0.03, "k_swt_inv_fused2<32, 1>": 0.06, "k_swt_inv_fused2<32, 2>": 0.06,                  # db11 ... db16 SWT
     }

@@ -21,7 +21,7 @@ for CFG in $CFGS; do
   for SET in "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INST_CYCLES_SALU SQ_WAVE_CYCLES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY" "SQ_INSTS_SMEM SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
     N=$(echo $SET | cut -d' ' -f1)
     D=$R/gpurun_out/pmc_${TAG}_${CFG}_$N; rm -rf $D
-    rocprofv3 --pmc $SET --kernel-trace -d $D -o t --output-format csv -- python $R/bench.py --config $CFG --steps 6 --warmup 2 --cpu-seconds 0 --no-roofline --no-others --settle-ms 0 > $D.log 2>&1
+    timeout 400 rocprofv3 --pmc $SET --kernel-trace -d $D -o t --output-format csv -- python $R/bench.py --config $CFG --steps 6 --warmup 2 --cpu-seconds 0 --no-roofline --no-others --settle-ms 0 > $D.log 2>&1
     python $R/tools/summarize_profile.py $D $OUT/${TAG}_${CFG}_pmc_sq_$N.md "${TAG}, config $CFG: rocprofv3 --pmc $SET --kernel-trace -- python bench.py --config $CFG --steps 6 --warmup 2 --no-others"
   done
   cat $OUT/${TAG}_${CFG}_pmc_sq_*.md > $OUT/${TAG}_${CFG}_pmc_sq.md 2>/dev/null; rm -f $OUT/${TAG}_${CFG}_pmc_sq_*.md
@@ -31,13 +31,13 @@ if echo "$CFGS" | grep -qw c2; then
   cd /tmp && export TMPDIR=/tmp
   # the same workload streaming through HBM: 16 images per step through the batched entry
   D=$R/gpurun_out/prof_${TAG}_c2_batch_kt; rm -rf $D
-  rocprofv3 --kernel-trace --stats -d $D -o t --output-format csv -- python $R/bench.py --config c2_batch --steps 40 --warmup 10 --cpu-seconds 0 --no-others > $D.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats -d $D -o t --output-format csv -- python $R/bench.py --config c2_batch --steps 40 --warmup 10 --cpu-seconds 0 --no-others > $D.log 2>&1
   grep '^{' $D.log | tail -1 > $OUT/${TAG}_c2_batch_bench_line.json
   python $R/tools/summarize_profile.py $D $OUT/${TAG}_c2_batch_kernel_trace.md "${TAG}, config c2_batch: rocprofv3 --kernel-trace --stats -- python bench.py --config c2_batch --steps 40 --warmup 10 --cpu-seconds 0 --no-others"
   for SET in "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INST_CYCLES_SALU SQ_WAVE_CYCLES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY"; do
     N=$(echo $SET | cut -d' ' -f1)
     D=$R/gpurun_out/pmc_${TAG}_c2_$N; rm -rf $D
-    rocprofv3 --pmc $SET --kernel-trace -d $D -o t --output-format csv -- python $R/bench.py --config c2 --steps 10 --warmup 3 --cpu-seconds 0 --no-roofline --no-others --settle-ms 0 > $D.log 2>&1
+    timeout 400 rocprofv3 --pmc $SET --kernel-trace -d $D -o t --output-format csv -- python $R/bench.py --config c2 --steps 10 --warmup 3 --cpu-seconds 0 --no-roofline --no-others --settle-ms 0 > $D.log 2>&1
     python $R/tools/summarize_profile.py $D $OUT/${TAG}_c2_pmc_sq_$N.md "${TAG}, config c2: rocprofv3 --pmc $SET --kernel-trace -- python bench.py --config c2 --steps 10 --warmup 3 --no-others"
   done
   cat $OUT/${TAG}_c2_pmc_sq_*.md > $OUT/${TAG}_c2_pmc_sq.md 2>/dev/null; rm -f $OUT/${TAG}_c2_pmc_sq_*.md
