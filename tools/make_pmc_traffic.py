@@ -15,7 +15,7 @@ import sys
 cfg, fdir, wdir = sys.argv[1], sys.argv[2], sys.argv[3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KMAP = {"k_fwd2d_casc": "fwd2d_casc", "k_inv2d_casc": "inv2d_casc", "k_inv2d_cascw": "inv2d_casc", "k_inv2d_casc3": "inv2d_casc", "k_fwd2d_stream": "fwd2d_stream", "k_fwd2d_fused": "fwd2d_fused", "k_inv2d_stream": "inv2d_stream", "k_inv2d_fused": "inv2d_fused",
-        "k_fwd2d_f64fused": "fwd2d_f64", "k_inv2d_f64fused": "inv2d_f64", "k_fwd2d_f64lds": "fwd2d_f64", "k_inv2d_f64lds": "inv2d_f64", "k_soft_thresh_sum": "thresh_sum", "k_soft_thresh": "soft_thresh", "k_abs_sum": "abs_sum",
+        "k_fwd2d_f64fused": "fwd2d_f64", "k_inv2d_f64fused": "inv2d_f64", "k_fwd2d_f64lds": "fwd2d_f64", "k_inv2d_f64lds": "inv2d_f64", "k_fwd2d_lat": "fwd2d_f64", "k_inv2d_lat": "inv2d_f64", "k_soft_thresh_sum": "thresh_sum", "k_soft_thresh": "soft_thresh", "k_abs_sum": "abs_sum",
         "k_ana_rows": "ana_rows", "k_ana_rows_tr": "ana_rows", "k_syn_rows_tr": "syn_rows", "k_ana_cols": "ana_cols", "k_syn_rows": "syn_rows", "k_syn_cols": "syn_cols",
         "k_fwd1d_stream": "ana_rows", "k_inv1d_stream": "syn_rows", "k_fwd1d_fused": "ana_rows", "k_inv1d_fused": "syn_rows", "k_inv1d_fused_pf": "syn_rows",
         "k_ana_cols_ring": "ana_cols", "k_ana_cols_ring_tr": "ana_cols", "k_syn_cols_ring": "syn_cols", "k_syn_cols_ring_tr": "syn_cols",
@@ -29,7 +29,7 @@ def collect(d, counter):
     for r in csv.DictReader(open(os.path.join(d, "t_counter_collection.csv"))):
         if r["Counter_Name"] != counter or "pdwt::" not in r["Kernel_Name"]:
             continue
-        base = r["Kernel_Name"].split("pdwt::")[1].split("<")[0].split("(")[0]
+        base = r["Kernel_Name"].split("<")[0].split("(")[0].split("::")[-1]  # (kernel name without namespaces: pdwt::nt::k_fwd1d_fused<...> -> k_fwd1d_fused)
         k = KMAP.get(base)
         if k:
             tot[k] += float(r["Counter_Value"])
