@@ -118,12 +118,25 @@ __device__ __forceinline__ void lat_tile(int strips, int chunks, int RO, int nro
         nout = min(RO, nrows - y0);
     }
 }
-__device__ __forceinline__ void asm_load(v2d& d, const char* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(d) : "v"(p) : "memory"); }
+#ifndef PDWT_LAT_NT  // (cache-policy experiments: bit 0 forward loads, bit 1 inverse loads, bit 2 forward stores, bit 3 inverse stores non-temporal)
+#define PDWT_LAT_NT 0
+#endif
+template <bool NT>
+__device__ __forceinline__ void asm_load(v2d& d, const char* p)
+{
+    if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(d) : "v"(p) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(d) : "v"(p) : "memory");
+}
+template <bool NT>
 __device__ __forceinline__ void st2_sv_m(double* b0, double* b1, unsigned boff, double v0, double v1, lanemask_t mask)
 {
     lanemask_t saved;
-    asm volatile("s_and_saveexec_b64 %0, %6\n\tglobal_store_dwordx2 %1, %2, %4\n\tglobal_store_dwordx2 %1, %3, %5\n\ts_mov_b64 exec, %0"
-                 : "=&s"(saved) : "v"(boff), "v"(v0), "v"(v1), "s"(b0), "s"(b1), "s"(mask) : "memory", "scc");
+    if constexpr (NT)
+        asm volatile("s_and_saveexec_b64 %0, %6\n\tglobal_store_dwordx2 %1, %2, %4 nt\n\tglobal_store_dwordx2 %1, %3, %5 nt\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(boff), "v"(v0), "v"(v1), "s"(b0), "s"(b1), "s"(mask) : "memory", "scc");
+    else
+        asm volatile("s_and_saveexec_b64 %0, %6\n\tglobal_store_dwordx2 %1, %2, %4\n\tglobal_store_dwordx2 %1, %3, %5\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(boff), "v"(v0), "v"(v1), "s"(b0), "s"(b1), "s"(mask) : "memory", "scc");
 }
 // all lanes when 0 <= i < n (one unsigned compare on the scalar unit), none otherwise
 __device__ __forceinline__ lanemask_t mask_in_range(int i, int n)
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(kNT, kWGPerCU) void k_fwd2d_lat(LatTable<LatGeo<HLE
         if constexpr (!(PDWT_LAT_DIAG & 1)) rnext += 8;
         rnext = rnext >= Nr ? rnext - Nr : rnext;
     };
-    auto load_one = [&](auto SL, auto MM) { asm_load(st[decltype(SL)::value][decltype(MM)::value], lp + gc[decltype(MM)::value]); };
+    auto load_one = [&](auto SL, auto MM) { asm_load<(PDWT_LAT_NT & 1) != 0>(st[decltype(SL)::value][decltype(MM)::value], lp + gc[decltype(MM)::value]); };
     auto load_rows = [&](auto SL) {
         load_begin();
         static_for<5>([&](auto MM) { load_one(SL, MM); });
@@ -365,7 +378,7 @@ __global__ __launch_bounds__(kNT, kWGPerCU) void k_fwd2d_lat(LatTable<LatGeo<HLE
             if constexpr (sec < 8 && (sec & 1)) {
                 // outputs of the step BEFORE the previous one's rows (kept in pu / pv): chunk-local pair qq -> band row y0 + qq - C; outside the chunk: EXEC = 0
                 constexpr int q = sec / 2;
-                st2_sv_m(spL, spH, ocol, pu[q], pv[q], mask_in_range(so, nout));
+                st2_sv_m<(PDWT_LAT_NT & 4) != 0>(spL, spH, ocol, pu[q], pv[q], mask_in_range(so, nout));
                 so++;
                 if constexpr (!(PDWT_LAT_DIAG & 2)) {
                     spL = reinterpret_cast<double*>(reinterpret_cast<char*>(spL) + spitch);
@@ -526,8 +539,8 @@ __global__ __launch_bounds__(kNT, kWGPerCU) void k_inv2d_lat(LatTable<LatGeo<HLE
     };
     auto load_one = [&](auto SL, auto MM) {
         constexpr int sl = decltype(SL)::value, m = decltype(MM)::value;
-        if constexpr (m & 1) asm_load(sb[sl][m / 2], lpb[m / 2]);
-        else asm_load(sa[sl][m / 2], lpa[m / 2]);
+        if constexpr (m & 1) asm_load<(PDWT_LAT_NT & 2) != 0>(sb[sl][m / 2], lpb[m / 2]);
+        else asm_load<(PDWT_LAT_NT & 2) != 0>(sa[sl][m / 2], lpa[m / 2]);
     };
     auto load_rows = [&](auto SL) {
         load_begin();
@@ -632,7 +645,7 @@ __global__ __launch_bounds__(kNT, kWGPerCU) void k_inv2d_lat(LatTable<LatGeo<HLE
                 // rows 2m + sig and 2m + sig + 1 of pair m = m0 + so; the second one wraps to row 0 for the image's last pair when sig = 1
                 double* r1p = reinterpret_cast<double*>(reinterpret_cast<char*>(sp0) + spitch);
                 if (sig && m0 + so == Nri - 1) r1p = out;  // (uniform)
-                st2_sv_m(sp0, r1p, ocol, pe[q], po[q], mask_in_range(so, nm));
+                st2_sv_m<(PDWT_LAT_NT & 8) != 0>(sp0, r1p, ocol, pe[q], po[q], mask_in_range(so, nm));
                 so++;
                 if constexpr (!(PDWT_LAT_DIAG & 2)) sp0 = reinterpret_cast<double*>(reinterpret_cast<char*>(sp0) + 2 * spitch);
             }
