@@ -466,6 +466,25 @@ def test_config4_batched_1d_shard_sym8_L4():
     assert band_err(out, x) <= 1e-5
 
 
+def test_config4_load_policy_variants_are_bit_identical():
+    """Round 6: batches that do not fit the Infinity Cache run the fused batched-1D kernels compiled with non-temporal row / band loads
+    (dwt1d_fused_nt.hip, knob dwt1d_nt_mb = 192 MB; C4's shard is 268 MB).  A cache policy, not arithmetic: every band and the
+    reconstruction equal the default-policy kernels bit for bit."""
+    from tests.helpers import knobs
+    rs = np.random.RandomState(4)
+    x = rs.randn(8192, 8192).astype(np.float32)
+    res = []
+    for mb in (192, 0):
+        with knobs(dwt1d_nt_mb=mb):
+            W = pdwt_amd.Wavelets(x, "sym8", 4, ndim=1)
+            W.forward()
+            c = W.coeffs
+            W.inverse()
+            res.append((c, W.get_image()))
+    assert all(np.array_equal(a, b) for a, b in zip(res[0][0], res[1][0])) and np.array_equal(res[0][1], res[1][1])
+    assert band_err(res[0][1], x) <= 1e-5
+
+
 def test_config5_f64_db20_L6_threshold_norm1_reduced():
     """configs[4] at 2048^2 (oracle-sized): f64 db20, clamp to the max level, threshold + norm1."""
     rs = np.random.RandomState(2)
